@@ -1,0 +1,312 @@
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE's own modules.
+
+Run in the build container only (the reference tree does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference/train/{erfnet,iouEval,erfnet_imagenet}.py, loads the
+closed-form weights of erfnet_pytorch_amd.synthetic into them and stores inputs-by-seed
+plus expected outputs.  No reference source or bytecode is written anywhere.  Large
+tensors are stored as a strided sample plus float64 sums (see `pack`).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/train")
+
+import erfnet as ref_erfnet                  # noqa: E402  (reference)
+import erfnet_imagenet as ref_imagenet       # noqa: E402  (reference)
+import iouEval as ref_iou                    # noqa: E402  (reference)
+
+from erfnet_pytorch_amd import synthetic as S  # noqa: E402
+
+torch.set_num_threads(8)
+MAX_FULL = 24000
+CITYSCAPES_WEIGHTS = [
+    2.8149201869965, 6.9850029945374, 3.7890393733978, 9.9428062438965, 9.7702074050903,
+    9.5110931396484, 10.311357498169, 10.026463508606, 4.6323022842407, 9.5608062744141,
+    7.8698215484619, 9.5168733596802, 10.373730659485, 6.6616044044495, 10.260489463806,
+    10.287888526917, 10.289801597595, 10.405355453491, 10.138095855713, 0.0,
+]
+
+
+def pack(out: dict, name: str, t: torch.Tensor):
+    """Store t fully if small, else a strided flat sample + sum + abs-sum (float64)."""
+    a = t.detach().cpu().contiguous()
+    flat = a.reshape(-1)
+    n = flat.numel()
+    stride = 1 if n <= MAX_FULL else -(-n // MAX_FULL)
+    out[name + "__shape"] = np.array(a.shape, dtype=np.int64)
+    out[name + "__stride"] = np.array(stride, dtype=np.int64)
+    out[name + "__sample"] = flat[::stride].numpy().copy()
+    if a.dtype.is_floating_point:
+        out[name + "__sum"] = np.array(flat.double().sum().item())
+        out[name + "__abssum"] = np.array(flat.double().abs().sum().item())
+
+
+def upstream(shape, seed):
+    n = int(np.prod(shape))
+    return torch.from_numpy(S.unit_uniform(n, S.key_seed("upstream", seed)).astype(np.float32).reshape(shape))
+
+
+def activations(shape, seed):
+    """Block inputs: non-negative-ish like post-ReLU maps, with exact zeros."""
+    n = int(np.prod(shape))
+    u = S.unit_uniform(n, S.key_seed("act", seed))
+    return torch.from_numpy(np.maximum(u * 1.5 - 0.2, 0).astype(np.float32).reshape(shape))
+
+
+def capture_masks(model):
+    """Forward hooks on every Dropout2d: recover the [N,C,1,1] multiplier actually applied."""
+    masks, handles = {}, []
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.Dropout2d) and mod.p != 0:
+            def hook(m, inp, out, name=name):
+                if m.training:
+                    keep = (out.detach().abs().sum(dim=(2, 3), keepdim=True) > 0).float()
+                    masks[name.rsplit(".dropout", 1)[0]] = keep / (1.0 - m.p)
+            handles.append(mod.register_forward_hook(hook))
+    return masks, handles
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_full_eval():
+    out = {}
+    for nc in (20, 6):
+        m = S.load_synthetic(ref_erfnet.ERFNet(nc)).eval()
+        for tag, (n, h, w, seed) in {"a": (1, 64, 128, 1), "b": (2, 128, 256, 2)}.items():
+            if nc == 6 and tag == "b":
+                continue
+            x = S.synthetic_images(n, h, w, seed=seed)
+            with torch.no_grad():
+                y = m(x)
+            top2 = y.topk(2, dim=1).values
+            out[f"nc{nc}_{tag}__in"] = np.array([n, h, w, seed], dtype=np.int64)
+            pack(out, f"nc{nc}_{tag}_logits", y)
+            out[f"nc{nc}_{tag}_argmax"] = y.max(1)[1].numpy().astype(np.uint8)
+            out[f"nc{nc}_{tag}_margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32)
+        if nc == 20:
+            x = S.synthetic_images(1, 64, 128, seed=1)
+            with torch.no_grad():
+                pack(out, "nc20_a_only_encode", m(x, only_encode=True))
+                pack(out, "nc20_a_encoder_feat", m.encoder(x))
+    np.savez_compressed(os.path.join(HERE, "g1_full_eval.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G2
+def block_case(out, tag, mod, prefix, x, seed, p_drop=0.0):
+    """Eval forward; train forward/backward with fixed upstream grad; running stats."""
+    sd = S.fill_state_dict({prefix + "." + k: v for k, v in mod.state_dict().items()})
+    mod.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items()})
+    out[tag + "__prefix"] = np.array(prefix)
+    out[tag + "__xshape"] = np.array(x.shape, dtype=np.int64)
+    out[tag + "__seed"] = np.array(seed, dtype=np.int64)
+    mod.eval()
+    with torch.no_grad():
+        pack(out, tag + "_y_eval", mod(x))
+    mod.train()
+    masks, handles = capture_masks(mod) if p_drop else ({}, [])
+    torch.manual_seed(1234 + seed)
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    dy = upstream(y.shape, seed)
+    y.backward(dy)
+    for h in handles:
+        h.remove()
+    pack(out, tag + "_y_train", y)
+    pack(out, tag + "_dx", xr.grad)
+    for k, v in mod.named_parameters():
+        pack(out, tag + "_grad_" + k, v.grad)
+    for k, v in mod.named_buffers():
+        if "num_batches" not in k:
+            pack(out, tag + "_buf_" + k, v)
+    for k, v in masks.items():
+        out[tag + "_mask"] = v.numpy()
+
+
+def g2_blocks():
+    out = {}
+    seed = 10
+    for (c, d, p, shape) in [(64, 1, 0.03, (2, 64, 24, 40)), (16, 1, 0.0, (2, 16, 24, 48)),
+                             (128, 2, 0.3, (2, 128, 16, 24)), (128, 4, 0.3, (2, 128, 16, 24)),
+                             (128, 8, 0.3, (2, 128, 24, 16)), (128, 16, 0.3, (1, 128, 40, 40)),
+                             (64, 1, 0.0, (1, 64, 16, 24))]:
+        seed += 1
+        mod = ref_erfnet.non_bottleneck_1d(c, p, d)
+        block_case(out, f"nb_c{c}_d{d}_p{int(p * 100)}", mod, f"blk{seed}", activations(shape, seed), seed, p)
+    for (cin, cout, shape) in [(3, 16, (2, 3, 32, 48)), (16, 64, (2, 16, 24, 32)), (64, 128, (2, 64, 16, 24))]:
+        seed += 1
+        x = S.synthetic_images(shape[0], shape[2], shape[3], seed=seed) if cin == 3 else activations(shape, seed)
+        block_case(out, f"down_{cin}_{cout}", ref_erfnet.DownsamplerBlock(cin, cout), f"blk{seed}", x, seed)
+    for (cin, cout, shape) in [(128, 64, (2, 128, 8, 12)), (64, 16, (2, 64, 12, 16))]:
+        seed += 1
+        # decoder upsampler weights are ConvTranspose2d: name the prefix so synthetic.fill_tensor scales them so
+        block_case(out, f"up_{cin}_{cout}", ref_erfnet.UpsamplerBlock(cin, cout), f"decoder.layers.{seed}",
+                   activations(shape, seed), seed)
+    for nc in (20, 6):
+        seed += 1
+        mod = torch.nn.ConvTranspose2d(16, nc, 2, stride=2, padding=0, output_padding=0, bias=True)
+        sd = S.fill_state_dict({"decoder.output_conv." + k: v for k, v in mod.state_dict().items()}, salt=seed)
+        mod.load_state_dict({k.rsplit(".", 1)[-1]: v for k, v in sd.items()})
+        x = activations((2, 16, 12, 16), seed).requires_grad_(True)
+        y = mod(x)
+        dy = upstream(y.shape, seed)
+        y.backward(dy)
+        tag = f"outconv_{nc}"
+        out[tag + "__seed"] = np.array(seed, dtype=np.int64)
+        pack(out, tag + "_y", y)
+        pack(out, tag + "_dx", x.grad)
+        pack(out, tag + "_grad_weight", mod.weight.grad)
+        pack(out, tag + "_grad_bias", mod.bias.grad)
+    np.savez_compressed(os.path.join(HERE, "g2_blocks.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G3
+def g3_loss():
+    out = {}
+    w = torch.tensor(CITYSCAPES_WEIGHTS, dtype=torch.float32)
+    for tag, (n, h, w_, seed, all_ignored) in {"mixed": (2, 16, 24, 31, False), "ignored": (1, 8, 8, 32, True)}.items():
+        z = (3.0 * upstream((n, 20, h, w_), seed)).requires_grad_(True)
+        t = S.synthetic_labels(n, h, w_, 20, seed=seed)[:, 0]
+        if all_ignored:
+            t = torch.full_like(t, 19)
+        crit = torch.nn.CrossEntropyLoss(w)
+        loss = crit(z, t)
+        loss.backward()
+        out[tag + "__in"] = np.array([n, h, w_, seed, int(all_ignored)], dtype=np.int64)
+        out[tag + "_loss"] = np.array(loss.item(), dtype=np.float32)
+        pack(out, tag + "_dlogits", z.grad)
+        # the nn.Module spelled out in the reference (log_softmax + NLLLoss) must agree
+        alt = torch.nn.NLLLoss(w)(torch.nn.functional.log_softmax(z.detach(), dim=1), t)
+        out[tag + "_loss_nll"] = np.array(alt.item(), dtype=np.float32)
+    # unweighted CE on class logits (imagenet/main.py:81)
+    z = (2.0 * upstream((8, 1000), 33)).requires_grad_(True)
+    t = S.synthetic_labels(8, 1, 1, 1000, seed=33, ignore_frac=0)[:, 0, 0, 0]
+    loss = torch.nn.CrossEntropyLoss()(z, t)
+    loss.backward()
+    out["cls_loss"] = np.array(loss.item(), dtype=np.float32)
+    pack(out, "cls_dlogits", z.grad)
+    np.savez_compressed(os.path.join(HERE, "g3_loss.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G4
+def g4_iou():
+    out = {}
+    for nc in (20, 6, 4):
+        ev = ref_iou.iouEval(nc)
+        for b in range(3):
+            seed = 40 + b
+            pred = S.synthetic_labels(2, 32, 48, nc, seed=seed + 100, ignore_frac=0.0)
+            lab = S.synthetic_labels(2, 32, 48, nc, seed=seed, ignore_frac=0.07 if nc == 20 else 0.0)
+            if nc == 20:   # predictions of the ignore class occur too (argmax can return 19)
+                pred = torch.where(S.synthetic_labels(2, 32, 48, 50, seed=seed + 200, ignore_frac=0) == 0,
+                                   torch.full_like(pred, 19), pred)
+            ev.addBatch(pred, lab)
+            out[f"nc{nc}_b{b}_tp"] = ev.tp.numpy().copy()
+            out[f"nc{nc}_b{b}_fp"] = ev.fp.numpy().copy()
+            out[f"nc{nc}_b{b}_fn"] = ev.fn.numpy().copy()
+        mean, per = ev.getIoU()
+        out[f"nc{nc}_iou_mean"] = np.array(mean.item())
+        out[f"nc{nc}_iou"] = per.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g4_iou.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G5
+def g5_train_steps():
+    out = {}
+    m = S.load_synthetic(ref_erfnet.ERFNet(20)).train()
+    w = torch.tensor(CITYSCAPES_WEIGHTS, dtype=torch.float32)
+    crit = torch.nn.CrossEntropyLoss(w)
+    opt = torch.optim.Adam(m.parameters(), 5e-4, (0.9, 0.999), eps=1e-08, weight_decay=1e-4)
+    num_epochs = 150
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: pow((1 - ((e - 1) / num_epochs)), 0.9))
+    masks, handles = capture_masks(m)
+    torch.manual_seed(5)
+    for step in range(3):
+        epoch = step + 1
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sched.step(epoch)
+        out[f"s{step}_lr"] = np.array(opt.param_groups[0]["lr"])
+        x = S.synthetic_images(2, 64, 128, seed=50 + step)
+        t = S.synthetic_labels(2, 64, 128, 20, seed=50 + step)
+        y = m(x)
+        opt.zero_grad()
+        loss = crit(y, t[:, 0])
+        loss.backward()
+        out[f"s{step}_loss"] = np.array(loss.item(), dtype=np.float32)
+        out[f"s{step}_masks__keys"] = np.array(sorted(masks.keys()))
+        for k in sorted(masks.keys()):
+            out[f"s{step}_mask_{k}"] = masks[k].numpy().copy()
+        names = [k for k, _ in m.named_parameters()]
+        out["param_names"] = np.array(names)
+        out[f"s{step}_gradnorm"] = np.array([(-1.0 if p.grad is None else p.grad.double().norm().item())
+                                             for _, p in m.named_parameters()])
+        if step == 0:
+            for k, p in m.named_parameters():
+                if p.grad is not None and (k.endswith("conv3x1_1.weight") and ("layers.1." in k or "layers.7." in k)
+                                           or "initial_block" in k or "output_conv" in k):
+                    pack(out, "s0_grad_" + k, p.grad)
+        opt.step()
+        out[f"s{step}_paramsum"] = np.array([p.detach().double().sum().item() for _, p in m.named_parameters()])
+        out[f"s{step}_paramabs"] = np.array([p.detach().double().abs().sum().item() for _, p in m.named_parameters()])
+        bn = [(k, b) for k, b in m.named_buffers() if "num_batches" not in k]
+        out["buffer_names"] = np.array([k for k, _ in bn])
+        out[f"s{step}_bufsum"] = np.array([b.double().sum().item() for _, b in bn])
+        pack(out, f"s{step}_logits", y)
+    st = opt.state[next(m.parameters())]
+    pack(out, "final_exp_avg_first", st["exp_avg"])
+    pack(out, "final_exp_avg_sq_first", st["exp_avg_sq"])
+    for h in handles:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "g5_train_steps.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G6
+def g6_imagenet():
+    out = {}
+    m = S.load_synthetic(ref_imagenet.ERFNet(1000)).eval()
+    x = S.synthetic_images(2, 224, 224, seed=60)
+    with torch.no_grad():
+        pack(out, "logits_eval", m(x))
+    m.train()
+    masks, handles = capture_masks(m)
+    torch.manual_seed(6)
+    t = S.synthetic_labels(2, 1, 1, 1000, seed=60, ignore_frac=0)[:, 0, 0, 0]
+    opt = torch.optim.SGD(m.parameters(), 0.1, momentum=0.9, weight_decay=1e-4)
+    y = m(x)
+    loss = torch.nn.CrossEntropyLoss()(y, t)
+    opt.zero_grad()
+    loss.backward()
+    out["loss"] = np.array(loss.item(), dtype=np.float32)
+    out["target"] = t.numpy()
+    pack(out, "logits_train", y)
+    out["param_names"] = np.array([k for k, _ in m.named_parameters()])
+    out["gradnorm"] = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    out["masks__keys"] = np.array(sorted(masks.keys()))
+    for k in sorted(masks.keys()):
+        out["mask_" + k] = masks[k].numpy().copy()
+    opt.step()
+    out["paramsum"] = np.array([p.detach().double().sum().item() for _, p in m.named_parameters()])
+    for h in handles:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "g6_imagenet.npz"), **out)
+
+
+if __name__ == "__main__":
+    g1_full_eval()
+    g2_blocks()
+    g3_loss()
+    g4_iou()
+    g5_train_steps()
+    g6_imagenet()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

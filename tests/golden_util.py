@@ -1,0 +1,67 @@
+"""Helpers shared by the parity tests: load tests/golden/*.npz and compare tensors
+against entries stored by tests/golden/make_golden.py's `pack` (strided sample + sums)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor, floor: float = 0.0) -> float:
+    """max |a-b| / max(max |b|, floor)  -- the 'relative error' used by every fp parity check.
+    `floor` gives quantities that are mathematically zero (a conv bias gradient in front of a
+    training-mode BatchNorm is pure cancellation noise) an absolute scale to be judged on."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    den = max(b.abs().max().item(), floor)
+    return (a - b).abs().max().item() / (den if den > 0 else 1.0)
+
+
+def check_packed(g, name, t: torch.Tensor, tol: float, what: str = "", floor: float = 0.0):
+    """Compare tensor t with the packed golden entry `name` (sample within tol relative
+    to the sample's max magnitude; global sum within tol * abssum)."""
+    shape = tuple(int(v) for v in g[name + "__shape"])
+    assert tuple(t.shape) == shape, f"{what}{name}: shape {tuple(t.shape)} != golden {shape}"
+    stride = int(g[name + "__stride"])
+    ref = torch.from_numpy(g[name + "__sample"])
+    flat = t.detach().cpu().contiguous().reshape(-1)
+    got = flat[::stride]
+    if ref.dtype.is_floating_point:
+        err = rel_err(got.float(), ref.float(), floor)
+        assert err <= tol, f"{what}{name}: sample rel err {err:.3e} > {tol:.1e}"
+        s = flat.double().sum().item()
+        gs, ga = float(g[name + "__sum"]), float(g[name + "__abssum"])
+        assert abs(s - gs) <= tol * max(ga, floor, 1e-30) * 4, f"{what}{name}: sum {s} vs golden {gs} (abssum {ga})"
+        return err
+    assert torch.equal(got, ref), f"{what}{name}: integer sample mismatch"
+    return 0.0
+
+
+def unpack_full(g, name) -> torch.Tensor:
+    assert int(g[name + "__stride"]) == 1, name + " was stored as a sample"
+    shape = tuple(int(v) for v in g[name + "__shape"])
+    return torch.from_numpy(g[name + "__sample"]).reshape(shape)
+
+
+def upstream(shape, seed):
+    from erfnet_pytorch_amd import synthetic as S
+    n = int(np.prod(shape))
+    return torch.from_numpy(S.unit_uniform(n, S.key_seed("upstream", seed)).astype(np.float32).reshape(shape))
+
+
+def activations(shape, seed):
+    from erfnet_pytorch_amd import synthetic as S
+    n = int(np.prod(shape))
+    u = S.unit_uniform(n, S.key_seed("act", seed))
+    return torch.from_numpy(np.maximum(u * 1.5 - 0.2, 0).astype(np.float32).reshape(shape))
+
+
+def pre_bn_bias(key: str) -> bool:
+    """True for a conv bias that feeds a training-mode BatchNorm directly: its gradient is
+    mathematically zero and what both sides hold is fp32 cancellation noise."""
+    return key.endswith(("conv1x3_1.bias", "conv1x3_2.bias", ".conv.bias")) or key in ("conv.bias",)

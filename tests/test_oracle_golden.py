@@ -1,0 +1,237 @@
+"""Pin the CPU oracle (oracle/erfnet_oracle.py) against the golden vectors that
+tests/golden/make_golden.py produced by executing the reference's own modules.
+CPU only; runs everywhere.  Tolerance 2e-6 relative: both sides are fp32 torch-CPU
+graphs of the same ops, differing at most in summation order."""
+import numpy as np
+import pytest
+import torch
+
+from erfnet_pytorch_amd import synthetic as S
+from oracle import erfnet_oracle as O
+from tests.golden_util import load, check_packed, activations, upstream, pre_bn_bias
+
+TOL = 2e-6
+torch.set_num_threads(8)
+
+
+def test_g1_full_eval_logits_and_argmax():
+    g = load("g1_full_eval.npz")
+    for nc, tags in ((20, ("a", "b")), (6, ("a",))):
+        sd = O.synthetic_state(O.erfnet_template(nc))
+        for tag in tags:
+            n, h, w, seed = (int(v) for v in g[f"nc{nc}_{tag}__in"])
+            x = S.synthetic_images(n, h, w, seed=seed)
+            with torch.no_grad():
+                y = O.erfnet(sd, x)
+            check_packed(g, f"nc{nc}_{tag}_logits", y, TOL)
+            am = O.argmax_labels(y)[:, 0].numpy().astype(np.uint8)
+            gold = g[f"nc{nc}_{tag}_argmax"]
+            margin = g[f"nc{nc}_{tag}_margin"]
+            # labels must agree wherever the reference's own top-2 margin exceeds fp32 noise
+            bad = (am != gold) & (margin > 1e-4)
+            assert not bad.any()
+            assert (am != gold).mean() < 1e-4
+    sd = O.synthetic_state(O.erfnet_template(20))
+    x = S.synthetic_images(1, 64, 128, seed=1)
+    with torch.no_grad():
+        check_packed(g, "nc20_a_only_encode", O.erfnet(sd, x, only_encode=True), TOL)
+        check_packed(g, "nc20_a_encoder_feat", O.encoder(sd, x, O.RunState()), TOL)
+
+
+def _block_cases():
+    g = load("g2_blocks.npz")
+    tags = sorted({k.split("__prefix")[0] for k in g.files if k.endswith("__prefix")})
+    return g, tags
+
+
+@pytest.mark.parametrize("tag", _block_cases()[1])
+def test_g2_block(tag):
+    g, _ = _block_cases()
+    prefix = str(g[tag + "__prefix"])
+    shape = tuple(int(v) for v in g[tag + "__xshape"])
+    seed = int(g[tag + "__seed"])
+    kind = tag.split("_")[0]
+    if kind == "nb":
+        c, d, p = int(tag.split("_")[1][1:]), int(tag.split("_")[2][1:]), int(tag.split("_")[3][1:]) / 100.0
+        tmpl = O.nb_template(prefix, c)
+        fwd = lambda sd, x, st: O.nb1d(sd, prefix, x, d, p, st)
+        x = activations(shape, seed)
+    elif kind == "down":
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        tmpl = O.down_template(prefix, cin, cout)
+        fwd = lambda sd, x, st: O.downsampler(sd, prefix, x, st)
+        x = S.synthetic_images(shape[0], shape[2], shape[3], seed=seed) if cin == 3 else activations(shape, seed)
+    else:
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        tmpl = O.up_template(prefix, cin, cout)
+        fwd = lambda sd, x, st: O.upsampler(sd, prefix, x, st)
+        x = activations(shape, seed)
+    sd = O.synthetic_state(tmpl)
+    with torch.no_grad():
+        check_packed(g, tag + "_y_eval", fwd(sd, x, O.RunState()), TOL)
+    leaf = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v)
+            for k, v in sd.items()}
+    masks = {prefix: torch.from_numpy(g[tag + "_mask"])} if (tag + "_mask") in g.files else {}
+    st = O.RunState(training=True, dropout_masks=masks)
+    xr = x.clone().requires_grad_(True)
+    y = fwd(leaf, xr, st)
+    y.backward(upstream(y.shape, seed))
+    check_packed(g, tag + "_y_train", y, TOL)
+    check_packed(g, tag + "_dx", xr.grad, 1e-5)
+    for k, v in leaf.items():
+        if v.requires_grad:
+            check_packed(g, tag + "_grad_" + k[len(prefix) + 1:], v.grad, 1e-5, floor=30.0 if pre_bn_bias(k) else 0.0)
+    for k, v in st.new_running.items():
+        if "num_batches" not in k:
+            check_packed(g, tag + "_buf_" + k[len(prefix) + 1:], v, TOL)
+
+
+@pytest.mark.parametrize("nc", [20, 6])
+def test_g2_output_conv(nc):
+    g = load("g2_blocks.npz")
+    tag = f"outconv_{nc}"
+    seed = int(g[tag + "__seed"])
+    w = S.fill_tensor("decoder.output_conv.weight", (16, nc, 2, 2), salt=seed).requires_grad_(True)
+    b = S.fill_tensor("decoder.output_conv.bias", (nc,), salt=seed).requires_grad_(True)
+    x = activations((2, 16, 12, 16), seed).requires_grad_(True)
+    y = torch.nn.functional.conv_transpose2d(x, w, b, stride=2)
+    y.backward(upstream(y.shape, seed))
+    check_packed(g, tag + "_y", y, TOL)
+    check_packed(g, tag + "_dx", x.grad, 1e-5)
+    check_packed(g, tag + "_grad_weight", w.grad, 1e-5)
+    check_packed(g, tag + "_grad_bias", b.grad, 1e-5)
+
+
+def test_g3_weighted_ce():
+    g = load("g3_loss.npz")
+    w = torch.tensor(O.CITYSCAPES_WEIGHTS, dtype=torch.float32)
+    for tag in ("mixed", "ignored"):
+        n, h, wd, seed, all_ign = (int(v) for v in g[tag + "__in"])
+        z = (3.0 * upstream((n, 20, h, wd), seed)).requires_grad_(True)
+        t = S.synthetic_labels(n, h, wd, 20, seed=seed)[:, 0]
+        if all_ign:
+            t = torch.full_like(t, 19)
+        loss = O.weighted_ce(z, t, w)
+        loss.backward()
+        gold = float(g[tag + "_loss"])
+        if all_ign:
+            assert np.isnan(gold) and torch.isnan(loss)      # 0/0 like torch
+        else:
+            assert abs(loss.item() - gold) <= 1e-6 * abs(gold)
+            assert abs(float(g[tag + "_loss_nll"]) - gold) <= 1e-6 * abs(gold)
+            check_packed(g, tag + "_dlogits", z.grad, 1e-5)
+    z = (2.0 * upstream((8, 1000), 33)).requires_grad_(True)
+    t = S.synthetic_labels(8, 1, 1, 1000, seed=33, ignore_frac=0)[:, 0, 0, 0]
+    loss = O.weighted_ce(z, t, None)
+    loss.backward()
+    assert abs(loss.item() - float(g["cls_loss"])) <= 1e-6 * abs(float(g["cls_loss"]))
+    check_packed(g, "cls_dlogits", z.grad, 1e-5)
+
+
+def test_g4_iou_counts_exact():
+    g = load("g4_iou.npz")
+    for nc in (20, 6, 4):
+        classes = nc - 1 if nc > 19 else nc
+        tp = torch.zeros(classes, dtype=torch.float64)
+        fp = torch.zeros(classes, dtype=torch.float64)
+        fn = torch.zeros(classes, dtype=torch.float64)
+        for b in range(3):
+            seed = 40 + b
+            pred = S.synthetic_labels(2, 32, 48, nc, seed=seed + 100, ignore_frac=0.0)
+            lab = S.synthetic_labels(2, 32, 48, nc, seed=seed, ignore_frac=0.07 if nc == 20 else 0.0)
+            if nc == 20:
+                pred = torch.where(S.synthetic_labels(2, 32, 48, 50, seed=seed + 200, ignore_frac=0) == 0,
+                                   torch.full_like(pred, 19), pred)
+            a, b_, c = O.iou_counts(pred, lab, nc)
+            tp += a
+            fp += b_
+            fn += c
+            assert np.array_equal(tp.numpy(), g[f"nc{nc}_b{b}_tp"])
+            assert np.array_equal(fp.numpy(), g[f"nc{nc}_b{b}_fp"])
+            assert np.array_equal(fn.numpy(), g[f"nc{nc}_b{b}_fn"])
+        mean, per = O.iou_from_counts(tp, fp, fn)
+        assert np.array_equal(per.numpy(), g[f"nc{nc}_iou"])
+        assert mean.item() == float(g[f"nc{nc}_iou_mean"])
+
+
+def test_g5_three_train_steps():
+    g = load("g5_train_steps.npz")
+    sd = O.synthetic_state(O.erfnet_template(20))
+    names = [str(s) for s in g["param_names"]]
+    bufnames = [str(s) for s in g["buffer_names"]]
+    w = torch.tensor(O.CITYSCAPES_WEIGHTS, dtype=torch.float32)
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    for step in range(3):
+        lr = O.poly_lr(5e-4, step + 1, 150)
+        assert abs(lr - float(g[f"s{step}_lr"])) < 1e-12
+        x = S.synthetic_images(2, 64, 128, seed=50 + step)
+        t = S.synthetic_labels(2, 64, 128, 20, seed=50 + step)[:, 0]
+        masks = {str(k): torch.from_numpy(g[f"s{step}_mask_{k}"]) for k in g[f"s{step}_masks__keys"]}
+        loss, grads, new_running, _, logits = O.train_step_grads(sd, x, t, w, masks)
+        gold_loss = float(g[f"s{step}_loss"])
+        assert abs(loss.item() - gold_loss) <= (2e-5, 1e-3, 1e-1)[step] * abs(gold_loss), (step, loss.item(), gold_loss)
+        # Measured on the reference itself: the same three steps run with 1 vs 8 CPU threads agree to
+        # 0 / 7e-5 / 1e-1 on the logits of steps 0 / 1 / 2 (Adam's first steps are ~lr*sign(g), so any
+        # parameter whose gradient is near fp32 noise moves by +-lr with an arbitrary sign).  Only the
+        # first two steps can therefore be pinned tightly; step 2 is a sanity bound.
+        if step < 2:
+            check_packed(g, f"s{step}_logits", logits, 2e-5 if step == 0 else 2e-3)
+        gn = g[f"s{step}_gradnorm"]
+        for i, k in enumerate(names):
+            if gn[i] < 0:
+                assert grads[k] is None           # encoder.output_conv is unused in the full forward
+            else:
+                mine = grads[k].double().norm().item()
+                if pre_bn_bias(k):               # mathematically zero: both sides hold noise
+                    assert mine < 1e-3 and gn[i] < 1e-3
+                    continue
+                # Adam turns the noise-only gradients of pre-BN biases into +-lr moves whose sign
+                # is arbitrary, so from the second step on the two trajectories differ by fp32 chaos
+                assert abs(mine - gn[i]) <= (2e-4, 1e-2, 0.5)[step] * max(gn[i], 1e-6), (step, k, mine, gn[i])
+        if step == 0:
+            for key in [f for f in g.files if f.startswith("s0_grad_") and f.endswith("__shape")]:
+                k = key[len("s0_grad_"):-len("__shape")]
+                check_packed(g, "s0_grad_" + k, grads[k], 1e-4)
+        O.adam_step([sd[k] for k in names], [grads[k] for k in names], m, v, step + 1, lr=lr)
+        sd.update(new_running)
+        ps = np.array([sd[k].double().sum().item() for k in names])
+        pa = g[f"s{step}_paramabs"]
+        keep = np.array([not pre_bn_bias(k) for k in names])
+        ptol = (2e-5, 2e-4, 2e-3)[step]
+        assert np.all((np.abs(ps - g[f"s{step}_paramsum"]) <= ptol * np.maximum(pa, 1e-3))[keep]), step
+        bs = np.array([sd[k].double().sum().item() for k in bufnames])
+        assert np.allclose(bs, g[f"s{step}_bufsum"], rtol=(2e-5, 2e-4, 2e-2)[step], atol=1e-4)
+    check_packed(g, "final_exp_avg_first", m[0], 0.2)
+    check_packed(g, "final_exp_avg_sq_first", v[0], 0.2)
+
+
+def test_g6_imagenet_encoder_classifier():
+    g = load("g6_imagenet.npz")
+    sd = O.synthetic_state(O.imagenet_template(1000))
+    x = S.synthetic_images(2, 224, 224, seed=60)
+    t = torch.from_numpy(g["target"])
+    with torch.no_grad():
+        check_packed(g, "logits_eval", O.erfnet_imagenet(sd, x), TOL * 5)
+    leaf = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v)
+            for k, v in sd.items()}
+    masks = {str(k): torch.from_numpy(g["mask_" + str(k)]) for k in g["masks__keys"]}
+    st = O.RunState(training=True, dropout_masks=masks)
+    y = O.erfnet_imagenet(leaf, x, st)
+    loss = O.weighted_ce(y, t, None)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    check_packed(g, "logits_train", y, 2e-5)
+    names = [str(s) for s in g["param_names"]]
+    gn = g["gradnorm"]
+    for i, k in enumerate(names):
+        mine = leaf[k].grad.double().norm().item()
+        if pre_bn_bias(k):
+            assert mine < 1e-3 and gn[i] < 1e-3
+            continue
+        assert abs(mine - gn[i]) <= 5e-4 * max(gn[i], 1e-6), (k, mine, gn[i])
+    params = [leaf[k].detach() for k in names]
+    bufs = [None] * len(names)
+    O.sgd_step(params, [leaf[k].grad for k in names], bufs)
+    ps = np.array([p.double().sum().item() for p in params])
+    assert np.allclose(ps, g["paramsum"], rtol=1e-4, atol=1e-4)
