@@ -1,0 +1,81 @@
+"""ctypes binding of libermi355.so (C ABI declared in include/erfnet_mi355.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  Importing this module
+without the built shared object raises, and every call checks the library's status code.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libermi355.so")
+
+F32, BF16 = 0, 1
+AXIS_H, AXIS_W = 0, 1
+
+_ERRORS = {-1: "invalid argument", -2: "unsupported shape or dtype", -3: "kernel launch failed"}
+
+
+class ErfError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C erfnet_pytorch_amd/csrc` (hipcc, --offload-arch=gfx950). There is no fallback path.")
+    return ctypes.CDLL(LIB_PATH)
+
+
+_lib = _load()
+
+P = c_void_p
+I = c_int
+LL = c_longlong
+
+# name -> (restype, argtypes); every int-returning entry is status-checked by `call`
+SIGNATURES = {
+    "erf_version": (I, []),
+    "erf_conv1d_packed_bytes": (c_size_t, [I, I]),
+    "erf_conv1d_pack": (I, [P, P, I, I, I, P]),
+    "erf_conv1d_factorized": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "erf_downsampler_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_downsampler_pack": (I, [P, P, I, I, I, P]),
+    "erf_downsampler": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "erf_stem_downsampler": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
+    "erf_upsampler_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_upsampler_pack": (I, [P, P, I, I, I, P]),
+    "erf_upsampler_convT3x3s2": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "erf_output_conv_packed_bytes": (c_size_t, [I, I]),
+    "erf_output_conv_pack": (I, [P, P, I, I, P]),
+    "erf_output_convT2x2s2": (I, [P, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "erf_pointwise_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_pointwise_pack": (I, [P, P, I, I, I, P]),
+    "erf_pointwise_conv": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "erf_nchw_to_nhwc": (I, [P, I, P, I, I, I, I, I, P]),
+    "erf_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
+    "erf_argmax_c": (I, [P, I, P, I, I, I, LL, P]),
+    "erf_iou_hist_accumulate": (I, [P, I, P, I, LL, I, P, P]),
+}
+
+_fn = {}
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(_lib, _name)          # AttributeError here = header and library out of sync
+    _f.restype = _res
+    _f.argtypes = _args
+    _fn[_name] = _f
+
+
+def call(name: str, *args):
+    """Invoke a status-returning entry point; raise ErfError on a non-zero status."""
+    rc = _fn[name](*args)
+    if rc != 0:
+        raise ErfError(f"{name} failed: {_ERRORS.get(rc, rc)}")
+
+
+def query(name: str, *args):
+    """Invoke a size/version query."""
+    return _fn[name](*args)

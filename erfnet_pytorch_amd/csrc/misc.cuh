@@ -1,0 +1,13 @@
+#pragma once
+#include <hip/hip_runtime.h>
+
+int stem_launch(const void* x, int x_dtype, void* y, const float* w, const float* scale, const float* shift, int dtype,
+                int N, int Hin, int Win, int relu, hipStream_t stream);
+int pool_affine_launch(const void* x, void* y, const float* scale, const float* shift, int dtype, int N, int Hin, int Win,
+                       int Cin, int ldy, int yoff, int relu, hipStream_t stream);
+int transpose_launch(const void* src, int sdt, void* dst, int ddt, int N, long long R, long long Cc, hipStream_t stream);
+int argmax_launch(const void* z, int dtype, void* lab, int label_bytes, int N, int C, long long HW, hipStream_t stream);
+int iou_hist_launch(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count, int nc,
+                    long long* hist, hipStream_t stream);
+int outconv_launch(const void* x, const void* packed, const float* bias, void* logits, int logits_f32, void* labels,
+                   int label_bytes, int dtype, int N, int Hin, int Win, int nc, hipStream_t stream);

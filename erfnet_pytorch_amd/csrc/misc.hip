@@ -1,0 +1,244 @@
+// Bandwidth-bound helper kernels: the 3->16 stem downsampler, the max-pool half of the
+// 16->64 / 64->128 downsamplers, layout conversion, arg-max and the IoU histogram.
+#include "common.cuh"
+#include "misc.cuh"
+
+// ------------------------------------------------------------------------------------------
+// Stem: NCHW [N,3,Hin,Win] -> NHWC [N,Hin/2,Win/2,16].  One thread per output pixel:
+// 13 conv3x3-s2 channels (27 inputs each) and 3 max-pool channels, affine + ReLU, one
+// 32-byte (bf16) / 64-byte (fp32) store.  The 351 weights sit in LDS and are read as
+// wave-wide broadcasts.
+template <typename TIN, typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T* __restrict__ y,
+                                                   const float* __restrict__ w, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, int N, int Hin, int Win, int relu,
+                                                   float* __restrict__ raw_out) {
+    __shared__ float sw[13 * 27 + 1];
+    __shared__ float ssc[16], ssh[16];
+    for (int i = threadIdx.x; i < 13 * 27; i += blockDim.x) sw[i] = w[i];
+    if (threadIdx.x < 16) {
+        ssc[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
+        ssh[threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    const int Ho = Hin >> 1, Wo = Win >> 1;
+    const long long P = (long long)N * Ho * Wo;
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P) return;
+    const int wo = (int)(pix % Wo);
+    const long long rest = pix / Wo;
+    const int ho = (int)(rest % Ho);
+    const int n = (int)(rest / Ho);
+    float in[27];
+    const long long plane = (long long)Hin * Win;
+    const TIN* xb = x + (long long)n * 3 * plane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int th = 0; th < 3; ++th)
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                const int hi = 2 * ho - 1 + th, wi = 2 * wo - 1 + tw;
+                float v = 0.f;
+                if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) v = Elem<TIN>::ld(xb + c * plane + (long long)hi * Win + wi);
+                in[c * 9 + th * 3 + tw] = v;
+            }
+    float out[16];
+#pragma unroll
+    for (int co = 0; co < 13; ++co) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) a = fmaf(sw[co * 27 + k], in[k], a);
+        out[co] = a;
+    }
+    // max-pool window (2ho..2ho+1, 2wo..2wo+1) = taps (th,tw) in {1,2}^2 of the 3x3 patch
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        out[13 + c] = fmaxf(fmaxf(in[c * 9 + 4], in[c * 9 + 5]), fmaxf(in[c * 9 + 7], in[c * 9 + 8]));
+    if (raw_out) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) raw_out[pix * 16 + c] = out[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float v = out[c] * ssc[c] + ssh[c];
+        out[c] = relu ? fmaxf(v, 0.f) : v;
+    }
+    T* yp = y + pix * 16;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) store4<T>(yp + c, f32x4{out[c], out[c + 1], out[c + 2], out[c + 3]});
+}
+
+int stem_launch(const void* x, int x_dtype, void* y, const float* w, const float* scale, const float* shift, int dtype,
+                int N, int Hin, int Win, int relu, hipStream_t stream) {
+    if ((Hin | Win) & 1) return ERF_EINVAL;
+    const long long P = (long long)N * (Hin / 2) * (Win / 2);
+    const unsigned grid = (unsigned)((P + 255) / 256);
+#define STEM(TIN, T) hipLaunchKernelGGL((stem_kernel<TIN, T>), dim3(grid), dim3(256), 0, stream, (const TIN*)x, (T*)y, w, scale, shift, N, Hin, Win, relu, (float*)nullptr)
+    if (x_dtype == 0 && dtype == 0) STEM(float, float);
+    else if (x_dtype == 0 && dtype == 1) STEM(float, bf16raw);
+    else if (x_dtype == 1 && dtype == 1) STEM(bf16raw, bf16raw);
+    else if (x_dtype == 1 && dtype == 0) STEM(bf16raw, float);
+    else return ERF_EUNSUPPORTED;
+#undef STEM
+    return erf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Max-pool 2x2 half of a downsampler: x NHWC [N,Hin,Win,Cin] -> channels [yoff, yoff+Cin) of
+// y NHWC [N,Hin/2,Win/2,ldy], with the block's affine + ReLU applied.  4 channels per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_affine_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int N, int Hin, int Win, int Cin, int ldy, int yoff, int relu) {
+    const int Ho = Hin >> 1, Wo = Win >> 1, C4 = Cin >> 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C4) * 4;
+    const long long pix = idx / C4;
+    const int wo = (int)(pix % Wo);
+    const long long rest = pix / Wo;
+    const int ho = (int)(rest % Ho);
+    const int n = (int)(rest / Ho);
+    const T* p00 = x + (((long long)n * Hin + 2 * ho) * Win + 2 * wo) * Cin + c;
+    f32x4 a = load4<T>(p00), b = load4<T>(p00 + Cin), d = load4<T>(p00 + (long long)Win * Cin),
+          e = load4<T>(p00 + (long long)Win * Cin + Cin);
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float m = fmaxf(fmaxf(a[k], b[k]), fmaxf(d[k], e[k]));
+        const float sc = scale ? scale[yoff + c + k] : 1.f, sh = shift ? shift[yoff + c + k] : 0.f;
+        m = m * sc + sh;
+        v[k] = relu ? fmaxf(m, 0.f) : m;
+    }
+    store4<T>(y + pix * ldy + yoff + c, v);
+}
+
+int pool_affine_launch(const void* x, void* y, const float* scale, const float* shift, int dtype, int N, int Hin, int Win,
+                       int Cin, int ldy, int yoff, int relu, hipStream_t stream) {
+    if (((Hin | Win) & 1) || (Cin & 3) || (yoff & 3) || (ldy & 3)) return ERF_EINVAL;
+    const long long total = (long long)N * (Hin / 2) * (Win / 2) * (Cin / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(pool_affine_kernel<bf16raw>, dim3(grid), dim3(256), 0, stream, (const bf16raw*)x, (bf16raw*)y,
+                           scale, shift, N, Hin, Win, Cin, ldy, yoff, relu);
+    else
+        hipLaunchKernelGGL(pool_affine_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, scale,
+                           shift, N, Hin, Win, Cin, ldy, yoff, relu);
+    return erf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout conversion through a 32x(32+1) LDS tile: [n][c][hw] <-> [n][hw][c].
+template <typename TS, typename TD>
+__global__ void transpose_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long R, long long Cc,
+                                 unsigned tiles_c, unsigned tiles_r) {
+    // src: [n][R][Cc] -> dst: [n][Cc][R]; blockIdx.x enumerates (n, tile_r, tile_c)
+    __shared__ float tile[32][33];
+    const unsigned tc = blockIdx.x % tiles_c;
+    const unsigned rest = blockIdx.x / tiles_c;
+    const unsigned tr = rest % tiles_r;
+    const unsigned n = rest / tiles_r;
+    const long long c0 = (long long)tc * 32;
+    const long long r0 = (long long)tr * 32;
+    const TS* s = src + (long long)n * R * Cc;
+    TD* d = dst + (long long)n * R * Cc;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const long long r = r0 + i;
+        const long long c = c0 + threadIdx.x;
+        if (r < R && c < Cc) tile[i][threadIdx.x] = Elem<TS>::ld(s + r * Cc + c);
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const long long c = c0 + i;
+        const long long r = r0 + threadIdx.x;
+        if (r < R && c < Cc) Elem<TD>::st(d + c * R + r, tile[threadIdx.x][i]);
+    }
+}
+
+int transpose_launch(const void* src, int sdt, void* dst, int ddt, int N, long long R, long long Cc, hipStream_t stream) {
+    const long long tiles_c = (Cc + 31) / 32, tiles_r = (R + 31) / 32;
+    const long long blocks = tiles_c * tiles_r * N;
+    if (blocks <= 0 || blocks > 0x7FFFFFFFLL) return ERF_EINVAL;
+    dim3 grid((unsigned)blocks), block(32, 8);
+#define TR(TS, TD) hipLaunchKernelGGL((transpose_kernel<TS, TD>), grid, block, 0, stream, (const TS*)src, (TD*)dst, R, Cc, (unsigned)tiles_c, (unsigned)tiles_r)
+    if (sdt == 0 && ddt == 0) TR(float, float);
+    else if (sdt == 0 && ddt == 1) TR(float, bf16raw);
+    else if (sdt == 1 && ddt == 0) TR(bf16raw, float);
+    else if (sdt == 1 && ddt == 1) TR(bf16raw, bf16raw);
+    else return ERF_EUNSUPPORTED;
+#undef TR
+    return erf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// arg-max over the class planes of NCHW logits; first maximum wins (strict > while scanning up).
+template <typename T, typename TL>
+__global__ __launch_bounds__(256) void argmax_kernel(const T* __restrict__ z, TL* __restrict__ lab, int C, long long HW,
+                                                     long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long long n = idx / HW, hw = idx % HW;
+    const T* p = z + n * C * HW + hw;
+    float best = Elem<T>::ld(p);
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = Elem<T>::ld(p + c * HW);
+        if (v > best) { best = v; bi = c; }
+    }
+    lab[idx] = (TL)bi;
+}
+
+int argmax_launch(const void* z, int dtype, void* lab, int label_bytes, int N, int C, long long HW, hipStream_t stream) {
+    const long long total = (long long)N * HW;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+#define AM(T, TL) hipLaunchKernelGGL((argmax_kernel<T, TL>), dim3(grid), dim3(256), 0, stream, (const T*)z, (TL*)lab, C, HW, total)
+    if (dtype == 0 && label_bytes == 8) AM(float, long long);
+    else if (dtype == 0 && label_bytes == 1) AM(float, unsigned char);
+    else if (dtype == 1 && label_bytes == 8) AM(bf16raw, long long);
+    else if (dtype == 1 && label_bytes == 1) AM(bf16raw, unsigned char);
+    else return ERF_EUNSUPPORTED;
+#undef AM
+    return erf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Confusion-matrix histogram: per-workgroup nc x nc counters in LDS (atomics), flushed with one
+// global 64-bit atomic per non-zero cell.  Grid-stride, 8 pixels per thread per trip.
+template <typename TP, typename TLB>
+__global__ __launch_bounds__(256) void iou_hist_kernel(const TP* __restrict__ pred, const TLB* __restrict__ label,
+                                                       long long count, int nc, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int sh[32 * 32 + 1];
+    const int cells = nc * nc + 1;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const long long g = (long long)label[i];
+        const long long p = (long long)pred[i];
+        const bool ok = g >= 0 && g < nc && p >= 0 && p < nc;
+        atomicAdd(&sh[ok ? (int)(g * nc + p) : nc * nc], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+        const unsigned int v = sh[i];
+        if (v) atomicAdd(&hist[i], (unsigned long long)v);
+    }
+}
+
+int iou_hist_launch(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count, int nc,
+                    long long* hist, hipStream_t stream) {
+    if (nc < 1 || nc > 32 || count < 0) return ERF_EINVAL;
+    if (count == 0) return ERF_OK;
+    long long blocks = (count + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+#define IH(TP, TLB) hipLaunchKernelGGL((iou_hist_kernel<TP, TLB>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TP*)pred, (const TLB*)label, count, nc, (unsigned long long*)hist)
+    if (pred_bytes == 1 && label_bytes == 8) IH(unsigned char, long long);
+    else if (pred_bytes == 8 && label_bytes == 8) IH(long long, long long);
+    else if (pred_bytes == 1 && label_bytes == 1) IH(unsigned char, unsigned char);
+    else if (pred_bytes == 8 && label_bytes == 1) IH(long long, unsigned char);
+    else return ERF_EUNSUPPORTED;
+#undef IH
+    return erf_check_launch();
+}

@@ -1,0 +1,17 @@
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct PackParams {
+    const float* src;
+    void* dst;
+    int cin;
+    int cout_virtual;       // rows that exist (others are zero)
+    int ncp;                // rows per weight "phase" (virtual channel = phase * ncp + cls)
+    int nc_valid;           // cls < nc_valid are real output channels
+    long long s_co, s_ci, s_phase;   // element strides in src
+    int ntaps;
+    int toff[9];            // element offset of each tap in src
+    int ct, ksteps;
+};
+
+int pack_launch(const PackParams& p, int dtype, hipStream_t stream);

@@ -1,0 +1,48 @@
+// Weight repacking: fp32 parameters in torch layout -> MFMA A-operand fragments.
+//
+// Packed layout of one phase: [ct][kstep][lane 0..63][16 bytes].  Lane (i = lane & 15,
+// q = lane >> 4) of (ct, kstep) holds, for output channel co = 16*ct + i, the 16-byte
+// chunk g = 4*kstep + q of that channel's K vector, K = (tap, ci) with ci fastest:
+// tap = g / CH, ci = (g % CH) * EPC + e, CH = Cin / EPC, EPC = 8 (bf16) or 4 (fp32).
+// Rows co >= Cout and chunks g >= ntaps * CH are zero.
+#include "common.cuh"
+#include "pack.cuh"
+
+template <typename T>
+__global__ void pack_kernel(const PackParams p) {
+    constexpr int EPC = Elem<T>::EPC;
+    const int CH = p.cin / EPC;
+    const long long total = (long long)p.ct * p.ksteps * 64;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long long rest = idx >> 6;
+    const int ks = (int)(rest % p.ksteps);
+    const int ct = (int)(rest / p.ksteps);
+    const int co = ct * 16 + (lane & 15);
+    const int g = ks * 4 + (lane >> 4);
+    const int tap = g / CH, chunk = g % CH;
+    const int phase = co / p.ncp, cls = co % p.ncp;
+    const bool ok = tap < p.ntaps && cls < p.nc_valid && co < p.cout_virtual;
+    T out[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        float v = 0.f;
+        if (ok) {
+            const int ci = chunk * EPC + e;
+            v = p.src[(long long)cls * p.s_co + (long long)phase * p.s_phase + (long long)ci * p.s_ci + p.toff[tap]];
+        }
+        out[e] = Elem<T>::from_f32(v);
+    }
+    *((i32x4*)p.dst + idx) = *(const i32x4*)out;
+}
+
+int pack_launch(const PackParams& p, int dtype, hipStream_t stream) {
+    const long long total = (long long)p.ct * p.ksteps * 64;
+    if (total <= 0) return ERF_EINVAL;
+    const int block = 256;
+    const int grid = (int)((total + block - 1) / block);
+    if (dtype == 1) hipLaunchKernelGGL(pack_kernel<bf16raw>, dim3(grid), dim3(block), 0, stream, p);
+    else hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(block), 0, stream, p);
+    return erf_check_launch();
+}

@@ -1,0 +1,196 @@
+"""Tensor-level wrappers over the C ABI (libermi355.so).
+
+Inside the package activations are NHWC tensors of shape [N,H,W,C] (contiguous, fp32 or
+bf16).  At the nn.Module boundary they appear as the logical [N,C,H,W] tensors the reference
+produces, backed by channels_last memory (a zero-copy permute of the NHWC tensor).
+All launches go to torch's current HIP stream, so they compose with torch ops, events and
+HIP-graph capture (torch.cuda.graph).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import AXIS_H, AXIS_W, BF16, F32, call, query
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"erfnet_pytorch_amd computes in float32 or bfloat16, got {t.dtype}")
+
+
+def tdtype(code: int) -> torch.dtype:
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def require_gpu(t: torch.Tensor, who: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: erfnet_pytorch_amd runs on MI355X (gfx950) device tensors only; "
+                           "got a CPU tensor and there is no CPU path in this package")
+
+
+# --------------------------------------------------------------------------- layout glue
+def to_nhwc(x: torch.Tensor, dtype: torch.dtype | None = None) -> torch.Tensor:
+    """Logical [N,C,H,W] -> NHWC tensor [N,H,W,C]; zero-copy when x is channels_last already."""
+    dtype = dtype or x.dtype
+    n, c, h, w = x.shape
+    if x.dtype == dtype and x.permute(0, 2, 3, 1).is_contiguous():
+        return x.permute(0, 2, 3, 1)
+    x = x.contiguous()
+    out = torch.empty((n, h, w, c), dtype=dtype, device=x.device)
+    call("erf_nchw_to_nhwc", x.data_ptr(), dt(x), out.data_ptr(), dt(out), n, c, h, w, _stream())
+    return out
+
+
+def to_nchw_view(y: torch.Tensor) -> torch.Tensor:
+    """NHWC tensor [N,H,W,C] -> logical [N,C,H,W] (channels_last strides), zero-copy."""
+    return y.permute(0, 3, 1, 2)
+
+
+def nhwc_to_nchw_contiguous(y: torch.Tensor, dtype: torch.dtype | None = None) -> torch.Tensor:
+    n, h, w, c = y.shape
+    out = torch.empty((n, c, h, w), dtype=dtype or y.dtype, device=y.device)
+    call("erf_nhwc_to_nchw", y.data_ptr(), dt(y), out.data_ptr(), dt(out), n, c, h, w, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- weight packing
+def _packed(nbytes: int, device) -> torch.Tensor:
+    if nbytes <= 0:
+        raise _lib.ErfError("unsupported layer shape for packing")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def pack_conv1d(w: torch.Tensor, code: int, mode: int = 0) -> torch.Tensor:
+    """w: Conv2d weight (C,C,3,1) or (C,C,1,3), fp32."""
+    c = w.shape[0]
+    w = w.detach().float().contiguous()
+    buf = _packed(query("erf_conv1d_packed_bytes", code, c), w.device)
+    call("erf_conv1d_pack", w.data_ptr(), buf.data_ptr(), code, c, mode, _stream())
+    return buf
+
+
+def pack_downsampler(w: torch.Tensor, code: int) -> torch.Tensor:
+    cc, cin = w.shape[0], w.shape[1]
+    w = w.detach().float().contiguous()
+    buf = _packed(query("erf_downsampler_packed_bytes", code, cin, cc + cin), w.device)
+    call("erf_downsampler_pack", w.data_ptr(), buf.data_ptr(), code, cin, cc + cin, _stream())
+    return buf
+
+
+def pack_upsampler(w: torch.Tensor, code: int) -> torch.Tensor:
+    cin, cout = w.shape[0], w.shape[1]
+    w = w.detach().float().contiguous()
+    buf = _packed(query("erf_upsampler_packed_bytes", code, cin, cout), w.device)
+    call("erf_upsampler_pack", w.data_ptr(), buf.data_ptr(), code, cin, cout, _stream())
+    return buf
+
+
+def pack_output_conv(w: torch.Tensor, code: int) -> torch.Tensor:
+    nc = w.shape[1]
+    w = w.detach().float().contiguous()
+    buf = _packed(query("erf_output_conv_packed_bytes", code, nc), w.device)
+    call("erf_output_conv_pack", w.data_ptr(), buf.data_ptr(), code, nc, _stream())
+    return buf
+
+
+def pack_pointwise(w: torch.Tensor, code: int) -> torch.Tensor:
+    nc, cin = w.shape[0], w.shape[1]
+    w = w.detach().float().contiguous()
+    buf = _packed(query("erf_pointwise_packed_bytes", code, cin, nc), w.device)
+    call("erf_pointwise_pack", w.data_ptr(), buf.data_ptr(), code, cin, nc, _stream())
+    return buf
+
+
+# --------------------------------------------------------------------------- forward ops (NHWC in, NHWC out)
+def conv1d(x, packed, scale, shift, residual, axis: int, dilation: int, relu: bool, out=None):
+    n, h, w, c = x.shape
+    y = torch.empty_like(x) if out is None else out
+    call("erf_conv1d_factorized", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), _p(residual),
+         dt(x), n, h, w, c, axis, dilation, int(relu), _stream())
+    return y
+
+
+def downsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None):
+    n, h, w, cin = x.shape
+    y = torch.empty((n, h // 2, w // 2, cout), dtype=x.dtype, device=x.device) if out is None else out
+    call("erf_downsampler", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), dt(x), n, h, w, cin, cout,
+         int(relu), _stream())
+    return y
+
+
+def stem(x_nchw, w, scale, shift, code: int, relu: bool = True, out=None):
+    n, c, h, w_ = x_nchw.shape
+    if c != 3:
+        raise ValueError("the initial block takes 3-channel images")
+    y = torch.empty((n, h // 2, w_ // 2, 16), dtype=tdtype(code), device=x_nchw.device) if out is None else out
+    call("erf_stem_downsampler", x_nchw.data_ptr(), dt(x_nchw), y.data_ptr(), w.data_ptr(), _p(scale), _p(shift), code,
+         n, h, w_, int(relu), _stream())
+    return y
+
+
+def upsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None):
+    n, h, w, cin = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device) if out is None else out
+    call("erf_upsampler_convT3x3s2", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), dt(x), n, h, w,
+         cin, cout, int(relu), _stream())
+    return y
+
+
+def output_conv(x, packed, bias, nc: int, want_logits: bool = True, logits_f32: bool = True, want_labels: bool = False,
+                label_dtype=torch.int64, logits_out=None, labels_out=None):
+    """Returns (logits NCHW or None, labels [N,2H,2W] or None)."""
+    n, h, w, cin = x.shape
+    logits = labels = None
+    if want_logits:
+        logits = logits_out if logits_out is not None else torch.empty(
+            (n, nc, 2 * h, 2 * w), dtype=torch.float32 if logits_f32 else x.dtype, device=x.device)
+    if want_labels:
+        labels = labels_out if labels_out is not None else torch.empty((n, 2 * h, 2 * w), dtype=label_dtype, device=x.device)
+    call("erf_output_convT2x2s2", x.data_ptr(), packed.data_ptr(), bias.data_ptr(), _p(logits),
+         int(logits is not None and logits.dtype == torch.float32), _p(labels),
+         0 if labels is None else labels.element_size(), dt(x), n, h, w, nc, _stream())
+    return logits, labels
+
+
+def pointwise(x, packed, bias, nc: int, out_f32: bool = True):
+    n, h, w, cin = x.shape
+    y = torch.empty((n, nc, h, w), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    call("erf_pointwise_conv", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(bias), int(out_f32), dt(x), n, h, w, cin,
+         nc, _stream())
+    return y
+
+
+# --------------------------------------------------------------------------- metrics
+def argmax_c(logits: torch.Tensor, label_dtype=torch.int64) -> torch.Tensor:
+    """outputs.max(1)[1] on NCHW-contiguous logits -> [N,H,W]."""
+    logits = logits.contiguous()
+    n, c, h, w = logits.shape
+    lab = torch.empty((n, h, w), dtype=label_dtype, device=logits.device)
+    call("erf_argmax_c", logits.data_ptr(), dt(logits), lab.data_ptr(), lab.element_size(), n, c, h * w, _stream())
+    return lab
+
+
+def iou_hist_accumulate(pred: torch.Tensor, label: torch.Tensor, nc: int, hist: torch.Tensor):
+    """hist (int64 [nc*nc+1], device) += confusion counts of (label, pred)."""
+    pred = pred.contiguous()
+    label = label.contiguous()
+    if pred.numel() != label.numel():
+        raise ValueError("prediction and label maps differ in size")
+    for t in (pred, label):
+        if t.dtype not in (torch.uint8, torch.int64):
+            raise TypeError("label maps must be uint8 or int64")
+    call("erf_iou_hist_accumulate", pred.data_ptr(), pred.element_size(), label.data_ptr(), label.element_size(),
+         pred.numel(), nc, hist.data_ptr(), _stream())
+    return hist

@@ -1,0 +1,199 @@
+"""GPU parity of the inference path (module API -> ctypes -> C ABI -> gfx950 kernels) against
+the CPU oracle and the golden vectors produced by the reference.
+
+Tolerances (relative to the reference tensor's max magnitude):
+  fp32 kernels: 1e-4 (north-star bar); the f32 MFMA is an exact fp32 fma chain, observed ~1e-6
+  bf16 kernels: 3e-2 per layer / 6e-2 end to end (8-bit mantissa activations and weights)
+Label maps: exact wherever the reference's own top-2 margin exceeds the logit tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from erfnet_pytorch_amd import synthetic as S
+from oracle import erfnet_oracle as O
+from tests.golden_util import load, check_packed, activations, rel_err
+
+pytestmark = pytest.mark.gpu
+FP32_TOL = 1e-4
+BF16_TOL = 3e-2
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(_dev(), dtype)
+
+
+def _back(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("c,shape", [(16, (2, 16, 12, 40)), (64, (2, 64, 20, 24)), (128, (1, 128, 40, 24))])
+@pytest.mark.parametrize("axis,dil", [(0, 1), (1, 1), (0, 2), (1, 4), (0, 16), (1, 16), (0, 8)])
+def test_conv1d_factorized(dtype, tol, c, shape, axis, dil):
+    from erfnet_pytorch_amd import ops
+    seed = 100 + c + axis * 7 + dil
+    x = activations(shape, seed) - 0.3
+    kshape = (c, c, 3, 1) if axis == 0 else (c, c, 1, 3)
+    w = S.fill_tensor("t.conv.weight", kshape, salt=seed)
+    b = S.fill_tensor("t.conv.bias", (c,), salt=seed)
+    sc = S.fill_tensor("t.bn.weight", (c,), salt=seed)
+    res = activations(shape, seed + 1)
+    pad, dl = ((dil, 0), (dil, 1)) if axis == 0 else ((0, dil), (1, dil))
+    ref = F.relu(F.conv2d(x, w, None, padding=pad, dilation=dl) * sc[None, :, None, None] + b[None, :, None, None] + res)
+    packed = ops.pack_conv1d(w.to(_dev()), ops.dt(torch.empty(0, dtype=dtype)))
+    y = ops.conv1d(_nhwc(x, dtype), packed, sc.to(_dev()), b.to(_dev()), _nhwc(res, dtype), axis, dil, True)
+    torch.cuda.synchronize()
+    assert rel_err(_back(y), ref) <= tol
+    # no scale, no residual, no relu
+    ref2 = F.conv2d(x, w, b, padding=pad, dilation=dl)
+    y2 = ops.conv1d(_nhwc(x, dtype), packed, None, b.to(_dev()), None, axis, dil, False)
+    assert rel_err(_back(y2), ref2) <= tol
+
+
+def _block_tags():
+    g = load("g2_blocks.npz")
+    return sorted({k.split("__prefix")[0] for k in g.files if k.endswith("__prefix")})
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("tag", _block_tags())
+def test_block_eval_vs_golden(tag, dtype, tol):
+    from erfnet_pytorch_amd import erfnet as E
+    g = load("g2_blocks.npz")
+    prefix = str(g[tag + "__prefix"])
+    shape = tuple(int(v) for v in g[tag + "__xshape"])
+    seed = int(g[tag + "__seed"])
+    kind = tag.split("_")[0]
+    if kind == "nb":
+        c, d, p = int(tag.split("_")[1][1:]), int(tag.split("_")[2][1:]), int(tag.split("_")[3][1:]) / 100.0
+        mod, tmpl, x = E.non_bottleneck_1d(c, p, d), O.nb_template(prefix, c), activations(shape, seed)
+    elif kind == "down":
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        mod, tmpl = E.DownsamplerBlock(cin, cout), O.down_template(prefix, cin, cout)
+        x = S.synthetic_images(shape[0], shape[2], shape[3], seed=seed) if cin == 3 else activations(shape, seed)
+    else:
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        mod, tmpl, x = E.UpsamplerBlock(cin, cout), O.up_template(prefix, cin, cout), activations(shape, seed)
+    sd = O.synthetic_state(tmpl)
+    mod.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items()})
+    mod = mod.to(_dev()).eval()
+    with torch.no_grad():
+        y = mod(x.to(_dev(), dtype))
+    assert y.shape == tuple(int(v) for v in g[tag + "_y_eval__shape"])
+    check_packed(g, tag + "_y_eval", y.float().cpu(), tol)
+
+
+@pytest.mark.parametrize("nc", [20, 6])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_output_conv_logits_and_fused_argmax(nc, dtype, tol):
+    from erfnet_pytorch_amd import ops
+    g = load("g2_blocks.npz")
+    tag = f"outconv_{nc}"
+    seed = int(g[tag + "__seed"])
+    w = S.fill_tensor("decoder.output_conv.weight", (16, nc, 2, 2), salt=seed)
+    b = S.fill_tensor("decoder.output_conv.bias", (nc,), salt=seed)
+    x = activations((2, 16, 12, 16), seed)
+    code = ops.dt(torch.empty(0, dtype=dtype))
+    packed = ops.pack_output_conv(w.to(_dev()), code)
+    logits, labels = ops.output_conv(_nhwc(x, dtype), packed, b.to(_dev()), nc, True, True, True)
+    check_packed(g, tag + "_y", logits.cpu(), tol)
+    # fused labels == argmax of the logits the same kernel wrote (bit-exact, first max wins)
+    assert torch.equal(labels.cpu(), logits.cpu().max(1)[1])
+    only_labels = ops.output_conv(_nhwc(x, dtype), packed, b.to(_dev()), nc, False, True, True, torch.uint8)[1]
+    assert torch.equal(only_labels.cpu().long(), labels.cpu())
+    assert torch.equal(ops.argmax_c(logits).cpu(), labels.cpu())
+
+
+def test_argmax_ties_first_index_wins():
+    from erfnet_pytorch_amd import ops
+    z = torch.zeros(1, 5, 4, 8)
+    z[0, 3, 1, :] = 2.0
+    z[0, 1, 1, :] = 2.0
+    z[0, 4, 2, 3] = -1.0
+    lab = ops.argmax_c(z.to(_dev())).cpu()
+    assert torch.equal(lab, z.max(1)[1])
+
+
+@pytest.mark.parametrize("nc,tags", [(20, ("a", "b")), (6, ("a",))])
+def test_full_net_fp32_vs_golden(nc, tags):
+    from erfnet_pytorch_amd import erfnet as E
+    g = load("g1_full_eval.npz")
+    model = E.ERFNet(nc)
+    model.load_state_dict(O.synthetic_state(O.erfnet_template(nc)))
+    model = model.to(_dev()).eval()
+    for tag in tags:
+        n, h, w, seed = (int(v) for v in g[f"nc{nc}_{tag}__in"])
+        x = S.synthetic_images(n, h, w, seed=seed).to(_dev())
+        with torch.no_grad():
+            y = model(x)
+            labels = model.predict_labels(x)
+        assert y.is_contiguous() and y.dtype == torch.float32
+        err = check_packed(g, f"nc{nc}_{tag}_logits", y.cpu(), FP32_TOL)
+        gold = torch.from_numpy(g[f"nc{nc}_{tag}_argmax"].astype(np.int64))
+        margin = torch.from_numpy(g[f"nc{nc}_{tag}_margin"])
+        lab = labels.cpu()
+        assert torch.equal(lab, y.cpu().max(1)[1])                 # fused arg-max == arg-max of our logits
+        amax = float(np.abs(g[f"nc{nc}_{tag}_logits__sample"]).max())
+        decided = margin > 2 * FP32_TOL * amax                        # reference's own top-2 gap above tolerance
+        assert torch.equal(lab[decided], gold[decided]), f"labels differ where margin is decisive (logit err {err:.2e})"
+        assert (lab != gold).float().mean().item() < 1e-3
+    if nc == 20:
+        x = S.synthetic_images(1, 64, 128, seed=1).to(_dev())
+        with torch.no_grad():
+            check_packed(g, "nc20_a_only_encode", model(x, only_encode=True).cpu(), FP32_TOL)
+            check_packed(g, "nc20_a_encoder_feat", model.encoder(x).float().cpu(), FP32_TOL)
+
+
+def test_full_net_bf16_vs_oracle():
+    from erfnet_pytorch_amd import erfnet as E
+    sd = O.synthetic_state(O.erfnet_template(20))
+    model = E.ERFNet(20)
+    model.load_state_dict(sd)
+    model = model.to(_dev()).eval()
+    model.compute_dtype = torch.bfloat16
+    x = S.synthetic_images(2, 128, 256, seed=7)
+    with torch.no_grad():
+        ref = O.erfnet(sd, x)
+        y = model(x.to(_dev()))
+        labels = model.predict_labels(x.to(_dev()))
+    assert y.dtype == torch.float32
+    err = rel_err(y.cpu(), ref)
+    assert err <= 6e-2, err
+    agree = (labels.cpu() == ref.max(1)[1]).float().mean().item()
+    assert agree > 0.90, agree                                        # stated bf16 label agreement on synthetic weights
+    assert torch.equal(labels.cpu(), y.cpu().max(1)[1])
+
+
+def test_iou_eval_exact_vs_golden_and_oracle():
+    from erfnet_pytorch_amd.iouEval import iouEval
+    g = load("g4_iou.npz")
+    for nc in (20, 6, 4):
+        ev = iouEval(nc)
+        for b in range(3):
+            seed = 40 + b
+            pred = S.synthetic_labels(2, 32, 48, nc, seed=seed + 100, ignore_frac=0.0)
+            lab = S.synthetic_labels(2, 32, 48, nc, seed=seed, ignore_frac=0.07 if nc == 20 else 0.0)
+            if nc == 20:
+                pred = torch.where(S.synthetic_labels(2, 32, 48, 50, seed=seed + 200, ignore_frac=0) == 0,
+                                   torch.full_like(pred, 19), pred)
+            ev.addBatch(pred.to(_dev()), lab.to(_dev()))
+            assert np.array_equal(ev.tp.numpy(), g[f"nc{nc}_b{b}_tp"])
+            assert np.array_equal(ev.fp.numpy(), g[f"nc{nc}_b{b}_fp"])
+            assert np.array_equal(ev.fn.numpy(), g[f"nc{nc}_b{b}_fn"])
+        mean, per = ev.getIoU()
+        assert np.array_equal(per.numpy(), g[f"nc{nc}_iou"])
+        assert mean.item() == float(g[f"nc{nc}_iou_mean"])
+    # uint8 predictions straight from the fused arg-max, larger map, against the oracle
+    pred = S.synthetic_labels(3, 128, 256, 20, seed=9, ignore_frac=0)
+    lab = S.synthetic_labels(3, 128, 256, 20, seed=10)
+    ev = iouEval(20)
+    ev.addBatch(pred.to(torch.uint8).to(_dev())[:, 0], lab.to(_dev()))
+    tp, fp, fn = O.iou_counts(pred, lab, 20)
+    assert torch.equal(ev.tp, tp) and torch.equal(ev.fp, fp) and torch.equal(ev.fn, fn)
+    assert int(ev.confusion().sum()) == pred.numel()
