@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_longlong, c_size_t, c_void_p
+from ctypes import c_double, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libermi355.so")
@@ -35,6 +35,9 @@ _lib = _load()
 P = c_void_p
 I = c_int
 LL = c_longlong
+F = c_float
+D = c_double
+ULL = c_ulonglong
 
 # name -> (restype, argtypes); every int-returning entry is status-checked by `call`
 SIGNATURES = {
@@ -59,7 +62,42 @@ SIGNATURES = {
     "erf_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
     "erf_argmax_c": (I, [P, I, P, I, I, I, LL, P]),
     "erf_iou_hist_accumulate": (I, [P, I, P, I, LL, I, P, P]),
+    # ---- training
+    "erf_bn_workspace_bytes": (c_size_t, [I]),
+    "erf_bn_stats_finalize": (I, [P, I, LL, I, P, P, P, P, F, F, P, P, P, P, P, P]),
+    "erf_bn_apply": (I, [P, P, P, P, P, P, P, I, I, LL, I, I, P]),
+    "erf_bn_backward": (I, [P, P, P, P, P, P, P, I, P, P, P, P, I, I, LL, I, P, P]),
+    "erf_relu_backward": (I, [P, P, P, I, LL, P]),
+    "erf_channel_sum": (I, [P, I, LL, I, P, P, P]),
+    "erf_dropout2d_mask": (I, [P, I, F, ULL, P]),
+    "erf_maxpool2x2_backward": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
+    "erf_ce_workspace_bytes": (c_size_t, []),
+    "erf_weighted_ce_fwd": (I, [P, I, P, P, I, I, LL, P, P, P]),
+    "erf_weighted_ce_bwd": (I, [P, I, P, P, I, I, LL, P, P, P]),
+    "erf_adam_fused_arena": (I, [P, P, P, P, LL, D, D, D, D, D, I, D, P]),
+    "erf_sgd_fused_arena": (I, [P, P, P, LL, D, D, D, I, D, P]),
+    "erf_conv1d_dgrad": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "erf_downsampler_dgrad_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_downsampler_dgrad_pack": (I, [P, P, I, I, I, P]),
+    "erf_downsampler_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "erf_upsampler_dgrad_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_upsampler_dgrad_pack": (I, [P, P, I, I, I, P]),
+    "erf_upsampler_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "erf_output_conv_patch_channels": (I, [I]),
+    "erf_output_conv_patches": (I, [P, I, P, I, I, I, I, I, P]),
+    "erf_output_conv_dgrad_packed_bytes": (c_size_t, [I, I]),
+    "erf_output_conv_dgrad_pack": (I, [P, P, I, I, P]),
+    "erf_output_conv_dgrad": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "erf_wgrad_workspace_bytes": (c_size_t, [I, I, I, LL]),
+    "erf_conv1d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, P, c_size_t, P]),
+    "erf_downsampler_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
+    "erf_image_to_nhwc_padded": (I, [P, I, P, I, I, I, I, P]),
+    "erf_stem_wgrad": (I, [P, P, P, I, I, I, I, P, c_size_t, P]),
+    "erf_upsampler_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
+    "erf_output_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P]),
 }
+# entry points whose int return value is data, not a status
+_PLAIN_INT = {"erf_version", "erf_output_conv_patch_channels"}
 
 _fn = {}
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,0 +1,337 @@
+"""Differentiable (training) path: one torch.autograd.Function per ERFNet block, every forward
+and backward computed by libermi355.so kernels.
+
+Semantics follow the reference modules in training mode (/root/reference/train/erfnet.py):
+BatchNorm2d with batch statistics and running-stat updates (eps 1e-3, momentum 0.1), Dropout2d
+masks per (image, channel), ReLU, residual add; in eval mode with gradients enabled the running
+statistics are used instead (frozen-BN fine-tuning).  Parameter gradients are fp32 tensors in
+the parameters' own torch layouts whatever the activation dtype (fp32 or bf16).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import AXIS_H, AXIS_W, BF16, F32, call, query
+
+_mask_counter = [0]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+# --------------------------------------------------------------------------- primitive wrappers
+def bn_forward_stats(z, bn, training):
+    """Returns (mean, invstd, scale, beta) for y = (z - mean)*scale + beta, scale = gamma*invstd; updates the
+    running statistics when training."""
+    c = z.shape[-1]
+    dev = z.device
+    gamma, beta = _f32(bn.weight), _f32(bn.bias)
+    if training:
+        mean = torch.empty(c, device=dev)
+        invstd = torch.empty(c, device=dev)
+        scale = torch.empty(c, device=dev)
+        shift = torch.empty(c, device=dev)
+        ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        call("erf_bn_stats_finalize", z.data_ptr(), ops.dt(z), z.numel() // c, c, gamma.data_ptr(), beta.data_ptr(),
+             _p(bn.running_mean if track else None), _p(bn.running_var if track else None), momentum, bn.eps,
+             mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream())
+        if track:
+            bn.num_batches_tracked += 1
+        return mean, invstd, scale, beta
+    invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+    scale = gamma * invstd
+    return bn.running_mean.float().contiguous(), invstd.contiguous(), scale.contiguous(), beta
+
+
+def bn_apply(z, center, scale, shift, residual=None, mask=None, relu=True):
+    """y = act(((z - center) * scale + shift) * mask + residual)"""
+    n, h, w, c = z.shape
+    y = torch.empty_like(z)
+    call("erf_bn_apply", z.data_ptr(), y.data_ptr(), _p(center), scale.data_ptr(), shift.data_ptr(), _p(residual), _p(mask),
+         ops.dt(z), n, h * w, c, int(relu), _stream())
+    return y
+
+
+def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=False):
+    n, h, w, c = z.shape
+    dev = z.device
+    dz = torch.empty_like(z)
+    g_out = torch.empty_like(z) if want_g_out else None
+    dgamma = torch.empty(c, device=dev)
+    dbeta = torch.empty(c, device=dev)
+    ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+    call("erf_bn_backward", g.data_ptr(), _p(gate), _p(mask), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+         gamma.data_ptr(), int(batch_stats), dz.data_ptr(), _p(g_out), dgamma.data_ptr(), dbeta.data_ptr(), ops.dt(z), n,
+         h * w, c, ws.data_ptr(), _stream())
+    return dz, g_out, dgamma, dbeta
+
+
+def channel_sum(z):
+    c = z.shape[-1]
+    out = torch.empty(c, device=z.device)
+    ws = _ws(query("erf_bn_workspace_bytes", c), z.device)
+    call("erf_channel_sum", z.data_ptr(), ops.dt(z), z.numel() // c, c, out.data_ptr(), ws.data_ptr(), _stream())
+    return out
+
+
+def conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation):
+    n, h, w, c = dy.shape
+    dx = torch.empty_like(dy)
+    call("erf_conv1d_dgrad", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), _p(gate), _p(residual), ops.dt(dy), n, h, w,
+         c, axis, dilation, _stream())
+    return dx
+
+
+def conv1d_wgrad(x, dz, wshape, axis, dilation):
+    n, h, w, c = x.shape
+    dw = torch.empty(wshape, device=x.device)
+    nb = query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
+    ws = _ws(nb, x.device)
+    call("erf_conv1d_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ops.dt(x), n, h, w, c, axis, dilation,
+         ws.data_ptr(), nb, _stream())
+    return dw
+
+
+def dropout_mask(n, c, p, dev, forced=None):
+    if forced is not None:
+        return forced.to(dev, torch.float32).reshape(n, c).contiguous()
+    _mask_counter[0] += 1
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _mask_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    mask = torch.empty(n * c, device=dev)
+    call("erf_dropout2d_mask", mask.data_ptr(), n * c, float(p), seed, _stream())
+    return mask.view(n, c)
+
+
+def _grad_nhwc(g, like):
+    """Incoming gradient (logical NCHW, any strides / dtype) -> NHWC tensor of the activations' dtype."""
+    return ops.to_nhwc(g, like.dtype)
+
+
+# --------------------------------------------------------------------------- non_bottleneck_1d
+class _NB1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, w1, b1, w2, b2, g1, be1, w3, b3, w4, b4, g2, be2):
+        xh = ops.to_nhwc(x)
+        code = ops.dt(xh)
+        d = mod.dilated
+        training = mod.training
+        a1 = ops.conv1d(xh, ops.pack_conv1d(w1, code), None, _f32(b1), None, AXIS_H, 1, True)
+        z2 = ops.conv1d(a1, ops.pack_conv1d(w2, code), None, _f32(b2), None, AXIS_W, 1, False)
+        mean1, invstd1, s1, t1 = bn_forward_stats(z2, mod.bn1, training)
+        a2 = bn_apply(z2, mean1, s1, t1)
+        a3 = ops.conv1d(a2, ops.pack_conv1d(w3, code), None, _f32(b3), None, AXIS_H, d, True)
+        z4 = ops.conv1d(a3, ops.pack_conv1d(w4, code), None, _f32(b4), None, AXIS_W, d, False)
+        mean2, invstd2, s2, t2 = bn_forward_stats(z4, mod.bn2, training)
+        mask = None
+        if training and mod.dropout.p != 0:
+            mask = dropout_mask(xh.shape[0], xh.shape[3], mod.dropout.p, xh.device, mod.__dict__.get("_erf_forced_mask"))
+        out = bn_apply(z4, mean2, s2, t2, residual=xh, mask=mask)
+        ctx.save_for_backward(xh, a1, z2, a2, a3, z4, out, mean1, invstd1, mean2, invstd2, w1, w2, w3, w4, g1, g2)
+        ctx.mask, ctx.d, ctx.training = mask, d, training
+        return ops.to_nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        xh, a1, z2, a2, a3, z4, out, mean1, invstd1, mean2, invstd2, w1, w2, w3, w4, g1, g2 = ctx.saved_tensors
+        code, d = ops.dt(xh), ctx.d
+        g = _grad_nhwc(gout, xh)
+        dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True)
+        db4 = channel_sum(dz4)
+        dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d)
+        dz3 = conv1d_dgrad(dz4, ops.pack_conv1d(w4, code, 1), a3, None, AXIS_W, d)
+        db3 = channel_sum(dz3)
+        dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d)
+        da2 = conv1d_dgrad(dz3, ops.pack_conv1d(w3, code, 1), None, None, AXIS_H, d)
+        dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training)
+        db2 = channel_sum(dz2)
+        dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1)
+        dz1 = conv1d_dgrad(dz2, ops.pack_conv1d(w2, code, 1), a1, None, AXIS_W, 1)
+        db1 = channel_sum(dz1)
+        dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1)
+        dx = conv1d_dgrad(dz1, ops.pack_conv1d(w1, code, 1), None, g_res, AXIS_H, 1)
+        return (ops.to_nchw_view(dx), None, dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)
+
+
+# --------------------------------------------------------------------------- DownsamplerBlock
+class _DownFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, w, b, gamma, beta):
+        code = ops.dt(x) if mod.ninput != 3 else getattr(mod, "_erf_code", ops.dt(x))
+        cin, cout = mod.ninput, mod.noutput
+        cc = cout - cin
+        shift = torch.zeros(cout, device=x.device)
+        shift[:cc] = b.detach().float()
+        if cin == 3:
+            img = x.contiguous()
+            z = ops.stem(img, _f32(w), None, shift, code, relu=False)
+            xh = img
+        else:
+            xh = ops.to_nhwc(x)
+            z = ops.downsampler(xh, ops.pack_downsampler(w, code), None, shift, cout, relu=False)
+        mean, invstd, s, t = bn_forward_stats(z, mod.bn, mod.training)
+        out = bn_apply(z, mean, s, t)
+        ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
+        ctx.cin, ctx.cout, ctx.training, ctx.code = cin, cout, mod.training, code
+        ctx.need_dx = x.requires_grad
+        return ops.to_nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        xh, z, out, mean, invstd, w, gamma = ctx.saved_tensors
+        cin, cout, code = ctx.cin, ctx.cout, ctx.code
+        cc = cout - cin
+        dev = z.device
+        g = _grad_nhwc(gout, z)
+        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training)
+        db = channel_sum(dz)[:cc].contiguous()
+        dw = torch.empty(w.shape, device=dev)
+        n, ho, wo, _ = z.shape
+        if cin == 3:
+            cpad = 8 if code == BF16 else 4
+            xpad = torch.empty((n, 2 * ho, 2 * wo, cpad), dtype=z.dtype, device=dev)
+            call("erf_image_to_nhwc_padded", xh.data_ptr(), ops.dt(xh), xpad.data_ptr(), code, n, 2 * ho, 2 * wo, _stream())
+            nb = query("erf_wgrad_workspace_bytes", 13, cpad, 9, n * ho * wo)
+            ws = _ws(nb, dev)
+            call("erf_stem_wgrad", xpad.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, ws.data_ptr(), nb,
+                 _stream())
+            return None, None, dw, db, dgamma, dbeta
+        nb = query("erf_wgrad_workspace_bytes", cc, cin, 9, n * ho * wo)
+        ws = _ws(nb, dev)
+        call("erf_downsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
+             ws.data_ptr(), nb, _stream())
+        dx = None
+        if ctx.need_dx:
+            pk = torch.empty(query("erf_downsampler_dgrad_packed_bytes", code, cin, cout), dtype=torch.uint8, device=dev)
+            call("erf_downsampler_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, cin, cout, _stream())
+            dxh = torch.empty_like(xh)
+            call("erf_downsampler_dgrad", dz.data_ptr(), dxh.data_ptr(), pk.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
+                 _stream())
+            call("erf_maxpool2x2_backward", xh.data_ptr(), dz.data_ptr(), dxh.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
+                 cc, 1, _stream())
+            dx = ops.to_nchw_view(dxh)
+        return dx, None, dw, db, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------- UpsamplerBlock
+class _UpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, w, b, gamma, beta):
+        xh = ops.to_nhwc(x)
+        code = ops.dt(xh)
+        z = ops.upsampler(xh, ops.pack_upsampler(w, code), None, _f32(b), mod.noutput, relu=False)
+        mean, invstd, s, t = bn_forward_stats(z, mod.bn, mod.training)
+        out = bn_apply(z, mean, s, t)
+        ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
+        ctx.training = mod.training
+        return ops.to_nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gout):
+        xh, z, out, mean, invstd, w, gamma = ctx.saved_tensors
+        code, dev = ops.dt(xh), xh.device
+        n, h, wd, cin = xh.shape
+        cout = z.shape[3]
+        g = _grad_nhwc(gout, z)
+        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training)
+        db = channel_sum(dz)
+        dw = torch.empty(w.shape, device=dev)
+        nb = query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)
+        ws = _ws(nb, dev)
+        call("erf_upsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, cout, ws.data_ptr(), nb,
+             _stream())
+        pk = torch.empty(query("erf_upsampler_dgrad_packed_bytes", code, cin, cout), dtype=torch.uint8, device=dev)
+        call("erf_upsampler_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, cin, cout, _stream())
+        dxh = torch.empty_like(xh)
+        call("erf_upsampler_dgrad", dz.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, cin, cout, _stream())
+        return ops.to_nchw_view(dxh), None, dw, db, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------- Decoder.output_conv
+class _OutConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, logits_f32):
+        xh = ops.to_nhwc(x)
+        code = ops.dt(xh)
+        nc = w.shape[1]
+        logits, _ = ops.output_conv(xh, ops.pack_output_conv(w, code), _f32(b), nc, True, logits_f32, False)
+        ctx.save_for_backward(xh, w)
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        xh, w = ctx.saved_tensors
+        code, dev = ops.dt(xh), xh.device
+        n, h, wd, _ = xh.shape
+        nc = w.shape[1]
+        glogits = glogits.contiguous()
+        ld = query("erf_output_conv_patch_channels", nc)
+        patches = torch.empty((n, h, wd, ld), dtype=xh.dtype, device=dev)
+        call("erf_output_conv_patches", glogits.data_ptr(), ops.dt(glogits), patches.data_ptr(), code, n, h, wd, nc, _stream())
+        db = channel_sum(patches)[: 4 * nc].reshape(nc, 4).sum(1)
+        dw = torch.empty(w.shape, device=dev)
+        nb = query("erf_wgrad_workspace_bytes", 4 * nc, 16, 1, n * h * wd)
+        ws = _ws(nb, dev)
+        call("erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc, ws.data_ptr(), nb,
+             _stream())
+        pk = torch.empty(query("erf_output_conv_dgrad_packed_bytes", code, nc), dtype=torch.uint8, device=dev)
+        call("erf_output_conv_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, nc, _stream())
+        dxh = torch.empty_like(xh)
+        call("erf_output_conv_dgrad", patches.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, nc, _stream())
+        return ops.to_nchw_view(dxh), dw, db, None
+
+
+# --------------------------------------------------------------------------- dispatch from the modules
+def block_forward(mod, x):
+    from . import erfnet as E
+    if isinstance(mod, E.non_bottleneck_1d):
+        return _NB1dFn.apply(x, mod, mod.conv3x1_1.weight, mod.conv3x1_1.bias, mod.conv1x3_1.weight, mod.conv1x3_1.bias,
+                             mod.bn1.weight, mod.bn1.bias, mod.conv3x1_2.weight, mod.conv3x1_2.bias, mod.conv1x3_2.weight,
+                             mod.conv1x3_2.bias, mod.bn2.weight, mod.bn2.bias)
+    if isinstance(mod, E.DownsamplerBlock):
+        return _DownFn.apply(x, mod, mod.conv.weight, mod.conv.bias, mod.bn.weight, mod.bn.bias)
+    if isinstance(mod, E.UpsamplerBlock):
+        return _UpFn.apply(x, mod, mod.conv.weight, mod.conv.bias, mod.bn.weight, mod.bn.bias)
+    raise TypeError(type(mod))
+
+
+def _compute_code(owner, x):
+    cd = getattr(owner, "compute_dtype", None)
+    return ops.dt(x) if cd is None else (BF16 if cd == torch.bfloat16 else F32)
+
+
+def encoder_forward(enc, x, predict=False, code=None):
+    if predict:
+        raise NotImplementedError("training through Encoder.output_conv (only_encode=True) is not built yet")
+    enc.initial_block.__dict__["_erf_code"] = _compute_code(enc, x) if code is None else code
+    y = block_forward(enc.initial_block, x)
+    for layer in enc.layers:
+        y = block_forward(layer, y)
+    return y
+
+
+def decoder_forward(dec, x, logits_f32=True):
+    y = x
+    for layer in dec.layers:
+        y = block_forward(layer, y)
+    return _OutConvFn.apply(y, dec.output_conv.weight, dec.output_conv.bias, logits_f32)
+
+
+def erfnet_forward(net, x):
+    feats = encoder_forward(net.encoder, x, code=_compute_code(net, x))
+    return decoder_forward(net.decoder, feats, logits_f32=x.dtype == torch.float32)

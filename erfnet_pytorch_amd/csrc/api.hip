@@ -38,7 +38,7 @@ int erf_conv1d_factorized(const void* x, void* y, const void* packed, const floa
     if (!x || !y || !packed || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || dilation < 1) return ERF_EINVAL;
     if (C != 16 && C != 64 && C != 128) return ERF_EUNSUPPORTED;
     if (axis != ERF_AXIS_H && axis != ERF_AXIS_W) return ERF_EINVAL;
-    int rc = conv1d_launch(x, y, packed, scale, shift, residual, dtype, N, H, W, C, axis, dilation, relu, (hipStream_t)stream);
+    int rc = conv1d_launch(x, y, packed, scale, shift, residual, nullptr, dtype, N, H, W, C, axis, dilation, relu, (hipStream_t)stream);
     if (rc != ERF_EUNSUPPORTED) return rc;
     GConvParams p{};
     p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual;

@@ -40,6 +40,7 @@ struct GConvParams {
     const float* scale;     // may be null (= 1)
     const float* shift;     // may be null (= 0)
     const void* res;        // residual, same geometry as y (NHWC modes only); may be null
+    const void* gate;       // NHWC mode: output zeroed where gate <= 0, before the residual add; may be null
     int N, Hin, Win, ldx, xoff;     // input: channel stride and first channel
     int Hb, Wb;                     // base grid
     int Hout, Wout, ldy, yoff;      // output: channel stride and first channel (NHWC) / total channels (NCHW)
@@ -150,6 +151,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
             if (p.out_mode == 0) {
                 T* yp = (T*)p.y + opix * p.ldy + p.yoff + co;
                 if (full) {
+                    if (p.gate) {
+                        f32x4 gv = load4<T>((const T*)p.gate + opix * p.ldy + p.yoff + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gv[e] > 0.f ? v[e] : 0.f;
+                    }
                     if (p.res) {
                         f32x4 rv = load4<T>((const T*)p.res + opix * p.ldy + p.yoff + co);
 #pragma unroll
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
                     for (int e = 0; e < 4; ++e)
                         if (co + e < p.Cout) {
                             float o = v[e];
+                            if (p.gate && !(Elem<T>::ld((const T*)p.gate + opix * p.ldy + p.yoff + co + e) > 0.f)) o = 0.f;
                             if (p.res) o += Elem<T>::ld((const T*)p.res + opix * p.ldy + p.yoff + co + e);
                             if (p.relu) o = fmaxf(o, 0.f);
                             Elem<T>::st(yp + e, o);

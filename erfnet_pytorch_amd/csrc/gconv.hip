@@ -26,6 +26,9 @@ int gconv_launch(const GConvParams& p, int dtype, int cin, hipStream_t stream) {
     GC_CASE(32, 8, 2)
     GC_CASE(48, 1, 4)
     GC_CASE(64, 1, 4)
+    GC_CASE(80, 1, 4)
+    GC_CASE(96, 1, 4)
+    GC_CASE(112, 1, 4)
     GC_CASE(64, 4, 4)
     GC_CASE(64, 8, 2)
     GC_CASE(128, 1, 4)

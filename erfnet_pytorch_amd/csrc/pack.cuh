@@ -5,6 +5,7 @@ struct PackParams {
     const float* src;
     void* dst;
     int cin;
+    int cin_valid;          // input channels >= cin_valid are zero / not written (0 = all valid)
     int cout_virtual;       // rows that exist (others are zero)
     int ncp;                // rows per weight "phase" (virtual channel = phase * ncp + cls)
     int nc_valid;           // cls < nc_valid are real output channels

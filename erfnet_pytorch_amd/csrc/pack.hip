@@ -30,7 +30,8 @@ __global__ void pack_kernel(const PackParams p) {
         float v = 0.f;
         if (ok) {
             const int ci = chunk * EPC + e;
-            v = p.src[(long long)cls * p.s_co + (long long)phase * p.s_phase + (long long)ci * p.s_ci + p.toff[tap]];
+            if (p.cin_valid == 0 || ci < p.cin_valid)
+                v = p.src[(long long)cls * p.s_co + (long long)phase * p.s_phase + (long long)ci * p.s_ci + p.toff[tap]];
         }
         out[e] = Elem<T>::from_f32(v);
     }

@@ -1,0 +1,48 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "pack.cuh"
+#include "gconv.cuh"
+
+size_t bn_workspace_bytes(int C);
+float* bn_workspace_coef(void* workspace, int C);
+int channel_sum_finalize_launch(const float* partials, int groups, int C, float* sums, hipStream_t stream);
+int bn_stats_launch(const void* z, int dtype, long long P, int C, float* partials, int* groups, hipStream_t stream);
+int bn_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                       float* scale, float* shift, hipStream_t stream);
+int bn_apply_launch(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* res, const float* mask,
+                    int dtype, long long P, int C, long long HW, int relu, hipStream_t stream);
+int bn_bwd_reduce_launch(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
+                         const float* invstd, int dtype, long long P, int C, long long HW, float* partials, int* groups,
+                         hipStream_t stream);
+int bn_bwd_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma,
+                           const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* coef, hipStream_t stream);
+int bn_bwd_apply_launch(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
+                        const float* invstd, const float* coef, void* dz, void* g_out, int dtype, long long P, int C,
+                        long long HW, hipStream_t stream);
+int relu_bwd_launch(const void* g, const void* gate, void* out, int dtype, long long total, hipStream_t stream);
+int dropout_mask_launch(float* mask, int count, float p, unsigned long long seed, hipStream_t stream);
+int pool_bwd_launch(const void* x, const void* dz, void* dx, int dtype, int N, int Hin, int Win, int Cin, int ldz, int zoff,
+                    int accumulate, hipStream_t stream);
+size_t ce_workspace_bytes();
+int ce_fwd_launch(const void* z, int dtype, const long long* target, const float* weight, int N, int C, long long HW,
+                  float* partials, float* out, hipStream_t stream);
+int ce_bwd_launch(const void* z, int dtype, const long long* target, const float* weight, int N, int C, long long HW,
+                  const float* coef, void* dz, hipStream_t stream);
+int adam_launch(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,
+                double wd, int step, double gscale, hipStream_t stream);
+int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, double momentum, double wd, int first,
+               double gscale, hipStream_t stream);
+int patches_launch(const void* dl, int src_dtype, void* out, int dtype, int N, int H, int W, int nc, int ncp, int ld,
+                   hipStream_t stream);
+int image_pad_launch(const void* x, int src_dtype, void* out, int dtype, int N, long long HW, int cpad, hipStream_t stream);
+
+// ---- weight gradients (wgrad.hip): dW[row][tap][ci] = sum_pixels dz[out pixel][row] * x[in pixel(tap)][ci]
+// Geometry is described like the forward gather conv (GConvParams: x = layer input, phases/taps),
+// `dz` is the gradient at the layer output (NHWC, channel stride lddz, first channel dzoff, `rows`
+// channels).  Partials go to `workspace`; the reduction writes fp32 gradients in torch layout
+// through the same index map the weight packer reads with (PackParams).
+size_t wgrad_workspace_bytes(int rows, int cin, int max_taps_per_phase, long long base_pixels);
+int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, int rows, int cin, const PackParams* maps,
+                 float* dw, float* workspace, size_t workspace_bytes, int dtype, hipStream_t stream);

@@ -1,0 +1,574 @@
+// Bandwidth-bound kernels of the training step: BatchNorm batch statistics / apply / backward,
+// Dropout2d mask, max-pool backward, weighted cross-entropy forward/backward, fused Adam/SGD.
+// All reductions are two-stage (per-workgroup partials in a caller-provided workspace, then a
+// one-block finalize in double precision): no float atomics, so results are bit-reproducible.
+#include "common.cuh"
+#include "train.cuh"
+
+#define RED_MAX_GROUPS 512
+
+// --------------------------------------------------------------------------------------------
+// Per-channel partial sums over an NHWC tensor.  MODE 0: (sum x, sum x^2).
+// MODE 1: BatchNorm backward sums (sum dy, sum dy * xhat) with dy = g * [act > 0] * mask[n][c].
+// Thread layout: C/4 channel groups x (256 / (C/4)) pixel lanes; 4 channels per thread.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ a, const T* __restrict__ gate,
+                                                          const float* __restrict__ mask, const T* __restrict__ z,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          long long P, int C, long long HW, float* __restrict__ partials) {
+    extern __shared__ double red[];     // [256][8]
+    const int C4 = C >> 2;
+    const int cg = threadIdx.x % C4, pl = threadIdx.x / C4;
+    const int PL = 256 / C4;            // pixel lanes per block (C4 <= 256 and divides 256 for C in {16,64,128})
+    const int c = cg * 4;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};      // fp64: E[x^2]-E[x]^2 must survive 39 stacked BatchNorms
+    f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
+    if (MODE == 1) { mu = *(const f32x4*)(mean + c); is = *(const f32x4*)(invstd + c); }
+    if (pl < PL) {
+        for (long long p = (long long)blockIdx.x * PL + pl; p < P; p += (long long)gridDim.x * PL) {
+            f32x4 v = load4<T>(a + p * C + c);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)v[e] * (double)v[e]; }
+            } else {
+                if (gate) {
+                    const f32x4 gt = load4<T>(gate + p * C + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gt[e] > 0.f ? v[e] : 0.f;
+                }
+                if (mask) {
+                    const f32x4 mk = *(const f32x4*)(mask + (p / HW) * C + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= mk[e];
+                }
+                const f32x4 zz = load4<T>(z + p * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)(v[e] * ((zz[e] - mu[e]) * is[e])); }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x * 8 + e] = s0[e]; red[threadIdx.x * 8 + 4 + e] = s1[e]; }
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+        for (int l = 0; l < PL; ++l)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { t0[e] += red[(l * C4 + cg) * 8 + e]; t1[e] += red[(l * C4 + cg) * 8 + 4 + e]; }
+        double* out = (double*)partials + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { out[c + e] = t0[e]; out[C + c + e] = t1[e]; }
+    }
+}
+
+static int red_groups(long long P, int C) {
+    const int PL = 256 / (C / 4);
+    long long g = (P + (long long)PL * 8 - 1) / ((long long)PL * 8);
+    if (g > RED_MAX_GROUPS) g = RED_MAX_GROUPS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// fp64 partials [RED_MAX_GROUPS][2C] followed by a 4C-float block for per-channel coefficients
+size_t bn_workspace_bytes(int C) { return (size_t)RED_MAX_GROUPS * 2 * C * sizeof(double) + 4 * C * sizeof(float); }
+float* bn_workspace_coef(void* workspace, int C) { return (float*)((double*)workspace + (size_t)RED_MAX_GROUPS * 2 * C); }
+
+__global__ void channel_sum_finalize_kernel(const double* __restrict__ partials, int groups, int C, float* __restrict__ sums) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0;
+        for (int g = 0; g < groups; ++g) s += partials[(long long)g * 2 * C + c];
+        sums[c] = (float)s;
+    }
+}
+
+int channel_sum_finalize_launch(const float* partials, int groups, int C, float* sums, hipStream_t stream) {
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(1), dim3(128), 0, stream, (const double*)partials, groups, C, sums);
+    return erf_check_launch();
+}
+
+static bool chan_ok(int C) { return C > 0 && (C & 3) == 0 && C <= 1024; }
+
+int bn_stats_launch(const void* z, int dtype, long long P, int C, float* partials, int* groups, hipStream_t stream) {
+    if (!chan_ok(C)) return ERF_EUNSUPPORTED;
+    const int g = red_groups(P, C);
+    *groups = g;
+    if (dtype == 1)
+        hipLaunchKernelGGL((chan_reduce_kernel<bf16raw, 0>), dim3(g), dim3(256), 256 * 8 * sizeof(double), stream,
+                           (const bf16raw*)z, (const bf16raw*)nullptr, (const float*)nullptr, (const bf16raw*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, P, C, 1LL, partials);
+    else
+        hipLaunchKernelGGL((chan_reduce_kernel<float, 0>), dim3(g), dim3(256), 256 * 8 * sizeof(double), stream,
+                           (const float*)z, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, P, C, 1LL, partials);
+    return erf_check_launch();
+}
+
+// mean / invstd / folded affine / running statistics from the partial sums (one block, double).
+__global__ void bn_finalize_kernel(const double* __restrict__ partials, int groups, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0, ss = 0;
+        for (int g = 0; g < groups; ++g) { s += partials[(long long)g * 2 * C + c]; ss += partials[(long long)g * 2 * C + C + c]; }
+        const double m = s / count;
+        double var = ss / count - m * m;
+        if (var < 0) var = 0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        mean[c] = (float)m;
+        invstd[c] = (float)is;
+        const double sc = (double)gamma[c] * is;
+        scale[c] = (float)sc;
+        shift[c] = (float)((double)beta[c] - m * sc);
+        if (running_mean) {
+            const double unbiased = count > 1 ? var * count / (count - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+    }
+}
+
+int bn_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                       float* scale, float* shift, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, stream, (const double*)partials, groups, C, (double)count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    return erf_check_launch();
+}
+
+// y = act( ((z - center) * scale + shift) * mask[n][c] + residual ); center may be null (= 0)
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ z, T* __restrict__ y,
+                                                         const float* __restrict__ center,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const T* __restrict__ res, const float* __restrict__ mask,
+                                                         long long total4, int C, long long HW, int relu) {
+    const int C4 = C >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long p = i / C4;
+        f32x4 v = load4<T>(z + i * 4);
+        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        if (center) {
+            const f32x4 ce = *(const f32x4*)(center + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] -= ce[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (mask) {
+            const f32x4 mk = *(const f32x4*)(mask + (p / HW) * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mk[e];
+        }
+        if (res) {
+            const f32x4 r = load4<T>(res + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+        }
+        if (relu)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        store4<T>(y + i * 4, v);
+    }
+}
+
+static unsigned ew_grid(long long total) {
+    long long g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+int bn_apply_launch(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* res, const float* mask,
+                    int dtype, long long P, int C, long long HW, int relu, hipStream_t stream) {
+    if (C & 3) return ERF_EUNSUPPORTED;
+    const long long total4 = P * (C / 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(affine_act_kernel<bf16raw>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const bf16raw*)z,
+                           (bf16raw*)y, center, scale, shift, (const bf16raw*)res, mask, total4, C, HW, relu);
+    else
+        hipLaunchKernelGGL(affine_act_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const float*)z, (float*)y,
+                           center, scale, shift, (const float*)res, mask, total4, C, HW, relu);
+    return erf_check_launch();
+}
+
+int bn_bwd_reduce_launch(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
+                         const float* invstd, int dtype, long long P, int C, long long HW, float* partials, int* groups,
+                         hipStream_t stream) {
+    if (!chan_ok(C)) return ERF_EUNSUPPORTED;
+    const int gr = red_groups(P, C);
+    *groups = gr;
+    if (dtype == 1)
+        hipLaunchKernelGGL((chan_reduce_kernel<bf16raw, 1>), dim3(gr), dim3(256), 256 * 8 * sizeof(double), stream,
+                           (const bf16raw*)g, (const bf16raw*)gate, mask, (const bf16raw*)z, mean, invstd, P, C, HW, partials);
+    else
+        hipLaunchKernelGGL((chan_reduce_kernel<float, 1>), dim3(gr), dim3(256), 256 * 8 * sizeof(double), stream,
+                           (const float*)g, (const float*)gate, mask, (const float*)z, mean, invstd, P, C, HW, partials);
+    return erf_check_launch();
+}
+
+// dgamma, dbeta and the three per-channel coefficients of dz = a * (dy - b - xhat * c)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int groups, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd, int batch_stats,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0, sx = 0;
+        for (int g = 0; g < groups; ++g) { s += partials[(long long)g * 2 * C + c]; sx += partials[(long long)g * 2 * C + C + c]; }
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)sx;
+        coef[c] = gamma[c] * invstd[c];
+        coef[C + c] = batch_stats ? (float)(s / count) : 0.f;
+        coef[2 * C + c] = batch_stats ? (float)(sx / count) : 0.f;
+    }
+}
+
+int bn_bwd_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma,
+                           const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* coef, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, stream, (const double*)partials, groups, C, (double)count, gamma,
+                       invstd, batch_stats, dgamma, dbeta, coef);
+    return erf_check_launch();
+}
+
+// dy = g * [gate > 0] * mask;  dz = a * (dy - b - xhat * c);  optionally g_out = g * [gate > 0]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ gate,
+                                                           const float* __restrict__ mask, const T* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, T* __restrict__ dz,
+                                                           T* __restrict__ g_out, long long total4, int C, long long HW) {
+    const int C4 = C >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long p = i / C4;
+        f32x4 v = load4<T>(g + i * 4);
+        if (gate) {
+            const f32x4 gt = load4<T>(gate + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gt[e] > 0.f ? v[e] : 0.f;
+        }
+        if (g_out) store4<T>(g_out + i * 4, v);
+        if (mask) {
+            const f32x4 mk = *(const f32x4*)(mask + (p / HW) * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mk[e];
+        }
+        const f32x4 zz = load4<T>(z + i * 4);
+        const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+        const f32x4 a = *(const f32x4*)(coef + c), b = *(const f32x4*)(coef + C + c), cc = *(const f32x4*)(coef + 2 * C + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = a[e] * (v[e] - b[e] - (zz[e] - mu[e]) * is[e] * cc[e]);
+        store4<T>(dz + i * 4, o);
+    }
+}
+
+int bn_bwd_apply_launch(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
+                        const float* invstd, const float* coef, void* dz, void* g_out, int dtype, long long P, int C,
+                        long long HW, hipStream_t stream) {
+    if (C & 3) return ERF_EUNSUPPORTED;
+    const long long total4 = P * (C / 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16raw>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const bf16raw*)g,
+                           (const bf16raw*)gate, mask, (const bf16raw*)z, mean, invstd, coef, (bf16raw*)dz, (bf16raw*)g_out,
+                           total4, C, HW);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const float*)g,
+                           (const float*)gate, mask, (const float*)z, mean, invstd, coef, (float*)dz, (float*)g_out, total4,
+                           C, HW);
+    return erf_check_launch();
+}
+
+// out = g * [gate > 0]  (ReLU backward on its own, for the conv -> ReLU -> conv links)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ g, const T* __restrict__ gate, T* __restrict__ out,
+                                                       long long total4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 v = load4<T>(g + i * 4);
+        const f32x4 gt = load4<T>(gate + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gt[e] > 0.f ? v[e] : 0.f;
+        store4<T>(out + i * 4, v);
+    }
+}
+
+int relu_bwd_launch(const void* g, const void* gate, void* out, int dtype, long long total, hipStream_t stream) {
+    if (total & 3) return ERF_EUNSUPPORTED;
+    const long long total4 = total / 4;
+    if (dtype == 1)
+        hipLaunchKernelGGL(relu_bwd_kernel<bf16raw>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const bf16raw*)g,
+                           (const bf16raw*)gate, (bf16raw*)out, total4);
+    else
+        hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const float*)g,
+                           (const float*)gate, (float*)out, total4);
+    return erf_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------
+// Dropout2d mask: mask[n][c] = Bernoulli(1 - p) / (1 - p), counter-based hash of (seed, index).
+__global__ void dropout_mask_kernel(float* __restrict__ mask, int count, float p, unsigned long long seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i + 1);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    const float u = (float)(x >> 40) * (1.0f / 16777216.0f);        // [0,1)
+    mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+int dropout_mask_launch(float* mask, int count, float p, unsigned long long seed, hipStream_t stream) {
+    if (count <= 0 || p < 0.f || p >= 1.f) return ERF_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, mask, count, p, seed);
+    return erf_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------
+// Max-pool 2x2 backward, accumulated into dx: dx[argmax of window] += dz[.., zoff + c].
+// Ties go to the first maximum in row-major window order (torch's max_pool2d_with_indices).
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dz, T* __restrict__ dx,
+                                                       int N, int Hin, int Win, int Cin, int ldz, int zoff, int accumulate) {
+    const int Ho = Hin >> 1, Wo = Win >> 1, C4 = Cin >> 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4) * 4;
+        const long long pix = idx / C4;
+        const int wo = (int)(pix % Wo);
+        const long long rest = pix / Wo;
+        const int ho = (int)(rest % Ho);
+        const int n = (int)(rest / Ho);
+        const long long o00 = (((long long)n * Hin + 2 * ho) * Win + 2 * wo) * Cin + c;
+        const long long offs[4] = {o00, o00 + Cin, o00 + (long long)Win * Cin, o00 + (long long)Win * Cin + Cin};
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = load4<T>(x + offs[k]);
+        const f32x4 g = load4<T>(dz + pix * ldz + zoff + c);
+        f32x4 o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int best = 0;
+            float bv = v[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k][e] > bv) { bv = v[k][e]; best = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][e] = best == k ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (accumulate) {
+                const f32x4 old = load4<T>(dx + offs[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[k][e] += old[e];
+            }
+            store4<T>(dx + offs[k], o[k]);
+        }
+    }
+}
+
+int pool_bwd_launch(const void* x, const void* dz, void* dx, int dtype, int N, int Hin, int Win, int Cin, int ldz, int zoff,
+                    int accumulate, hipStream_t stream) {
+    if (((Hin | Win) & 1) || (Cin & 3) || (ldz & 3) || (zoff & 3)) return ERF_EINVAL;
+    const long long total = (long long)N * (Hin / 2) * (Win / 2) * (Cin / 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(pool_bwd_kernel<bf16raw>, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16raw*)x,
+                           (const bf16raw*)dz, (bf16raw*)dx, N, Hin, Win, Cin, ldz, zoff, accumulate);
+    else
+        hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)x,
+                           (const float*)dz, (float*)dx, N, Hin, Win, Cin, ldz, zoff, accumulate);
+    return erf_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------
+// Weighted cross-entropy over NCHW logits (one thread per pixel, class planes read coalesced).
+// fwd: partial (sum w[t]*nll, sum w[t]) per block -> finalize writes {num, den, num/den}.
+// bwd: dlogits[c] = coefficient * w[t] * (softmax[c] - [c == t]), coefficient read from device memory.
+template <typename T, int BWD>
+__global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ z, const long long* __restrict__ target,
+                                                 const float* __restrict__ weight, int C, long long HW, long long total,
+                                                 float* __restrict__ partials, const float* __restrict__ coef,
+                                                 T* __restrict__ dz) {
+    __shared__ float rs[256], rw[256];
+    float acc_l = 0.f, acc_w = 0.f;
+    const float k = BWD ? coef[0] : 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long n = idx / HW, hw = idx % HW;
+        const T* p = z + n * C * HW + hw;
+        const long long t = target[idx];
+        const bool valid = t >= 0 && t < C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, Elem<T>::ld(p + c * HW));
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(p + c * HW) - m);
+        const float w = valid ? (weight ? weight[t] : 1.f) : 0.f;
+        if (!BWD) {
+            if (valid) {
+                const float zt = Elem<T>::ld(p + t * HW);
+                acc_l += w * (m + __logf(se) - zt);
+                acc_w += w;
+            }
+        } else {
+            const float inv = 1.f / se;
+            T* q = dz + n * C * HW + hw;
+            for (int c = 0; c < C; ++c) {
+                const float sm = __expf(Elem<T>::ld(p + c * HW) - m) * inv;
+                Elem<T>::st(q + c * HW, k * w * (sm - (c == t ? 1.f : 0.f)));
+            }
+        }
+    }
+    if (!BWD) {
+        rs[threadIdx.x] = acc_l; rw[threadIdx.x] = acc_w;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) { rs[threadIdx.x] += rs[threadIdx.x + s]; rw[threadIdx.x] += rw[threadIdx.x + s]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rs[0]; partials[2 * blockIdx.x + 1] = rw[0]; }
+    }
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ partials, int groups, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0;
+        for (int g = 0; g < groups; ++g) { a += partials[2 * g]; b += partials[2 * g + 1]; }
+        out[0] = (float)a; out[1] = (float)b; out[2] = (float)(a / b);
+    }
+}
+
+size_t ce_workspace_bytes() { return (size_t)RED_MAX_GROUPS * 2 * sizeof(float); }
+
+int ce_fwd_launch(const void* z, int dtype, const long long* target, const float* weight, int N, int C, long long HW,
+                  float* partials, float* out, hipStream_t stream) {
+    const long long total = (long long)N * HW;
+    long long g = (total + 256 * 4 - 1) / (256 * 4);
+    if (g > RED_MAX_GROUPS) g = RED_MAX_GROUPS;
+    if (g < 1) g = 1;
+    if (dtype == 1)
+        hipLaunchKernelGGL((ce_kernel<bf16raw, 0>), dim3((unsigned)g), dim3(256), 0, stream, (const bf16raw*)z, target, weight,
+                           C, HW, total, partials, (const float*)nullptr, (bf16raw*)nullptr);
+    else
+        hipLaunchKernelGGL((ce_kernel<float, 0>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)z, target, weight, C,
+                           HW, total, partials, (const float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, (int)g, out);
+    return erf_check_launch();
+}
+
+int ce_bwd_launch(const void* z, int dtype, const long long* target, const float* weight, int N, int C, long long HW,
+                  const float* coef, void* dz, hipStream_t stream) {
+    const long long total = (long long)N * HW;
+    if (dtype == 1)
+        hipLaunchKernelGGL((ce_kernel<bf16raw, 1>), dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16raw*)z, target,
+                           weight, C, HW, total, (float*)nullptr, coef, (bf16raw*)dz);
+    else
+        hipLaunchKernelGGL((ce_kernel<float, 1>), dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)z, target, weight,
+                           C, HW, total, (float*)nullptr, coef, (float*)dz);
+    return erf_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------
+// Fused optimiser steps over a flat fp32 arena (4 elements per thread).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float step_size, float b1, float omb1,
+                                                   float b2, float omb2, float eps, float wd, float bc2_sqrt, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;                 // coupled L2 decay (torch.optim.Adam)
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+int adam_launch(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,
+                double wd, int step, double gscale, hipStream_t stream) {
+    if (n <= 0 || step < 1) return ERF_EINVAL;
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2s = sqrt(1.0 - pow(b2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, n, (float)(lr / bc1), (float)b1,
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, (float)bc2s, (float)gscale);
+    return erf_check_launch();
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  long long n, float lr, float momentum, float wd, int first, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;
+        const float bi = first ? gi : momentum * buf[i] + gi;
+        buf[i] = bi;
+        p[i] = pi - lr * bi;
+    }
+}
+
+int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, double momentum, double wd, int first,
+               double gscale, hipStream_t stream) {
+    if (n <= 0) return ERF_EINVAL;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, buf, n, (float)lr, (float)momentum, (float)wd,
+                       first, (float)gscale);
+    return erf_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------
+// dlogits NCHW [N,nc,2H,2W] -> "patch" NHWC [N,H,W,ld] (channel = 4*class + phase, phase = 2a+b
+// the position inside the 2x2 output patch; channels >= 4*nc zero), the layout output_conv's
+// backward GEMMs take.  `ncp` = ld / 4.
+template <typename TS, typename T>
+__global__ __launch_bounds__(256) void patches_kernel(const TS* __restrict__ dl, T* __restrict__ out, int N, int H, int W,
+                                                      int nc, int ncp, int ld) {
+    const long long total = (long long)N * H * W * 4 * ncp;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        // iterate with the pixel fastest so that plane reads coalesce
+        const long long P = (long long)N * H * W;
+        const long long pix = idx % P;
+        const int v = (int)(idx / P);
+        const int cls = v >> 2, ph = v & 3;
+        const int j = (int)(pix % W);
+        const long long rest = pix / W;
+        const int i = (int)(rest % H);
+        const int n = (int)(rest / H);
+        float val = 0.f;
+        if (cls < nc)
+            val = Elem<TS>::ld(dl + (((long long)n * nc + cls) * (2 * H) + 2 * i + (ph >> 1)) * (2 * W) + 2 * j + (ph & 1));
+        Elem<T>::st(out + pix * ld + v, val);
+    }
+}
+
+int patches_launch(const void* dl, int src_dtype, void* out, int dtype, int N, int H, int W, int nc, int ncp, int ld,
+                   hipStream_t stream) {
+    const long long total = (long long)N * H * W * 4 * ncp;
+#define PK(TS, T) hipLaunchKernelGGL((patches_kernel<TS, T>), dim3(ew_grid(total)), dim3(256), 0, stream, (const TS*)dl, (T*)out, N, H, W, nc, ncp, ld)
+    if (src_dtype == 0 && dtype == 0) PK(float, float);
+    else if (src_dtype == 0 && dtype == 1) PK(float, bf16raw);
+    else if (src_dtype == 1 && dtype == 1) PK(bf16raw, bf16raw);
+    else if (src_dtype == 1 && dtype == 0) PK(bf16raw, float);
+    else return ERF_EUNSUPPORTED;
+#undef PK
+    return erf_check_launch();
+}
+
+// image NCHW [N,3,H,W] -> NHWC [N,H,W,cpad] (channels >= 3 zero), operand of the stem's weight gradient
+template <typename TS, typename T>
+__global__ __launch_bounds__(256) void image_pad_kernel(const TS* __restrict__ x, T* __restrict__ out, long long N, long long HW,
+                                                        int cpad) {
+    const long long total = N * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long n = idx / HW, hw = idx % HW;
+        for (int c = 0; c < cpad; ++c)
+            Elem<T>::st(out + idx * cpad + c, c < 3 ? Elem<TS>::ld(x + (n * 3 + c) * HW + hw) : 0.f);
+    }
+}
+
+int image_pad_launch(const void* x, int src_dtype, void* out, int dtype, int N, long long HW, int cpad, hipStream_t stream) {
+    const long long total = (long long)N * HW;
+#define IP(TS, T) hipLaunchKernelGGL((image_pad_kernel<TS, T>), dim3(ew_grid(total)), dim3(256), 0, stream, (const TS*)x, (T*)out, (long long)N, HW, cpad)
+    if (src_dtype == 0 && dtype == 0) IP(float, float);
+    else if (src_dtype == 0 && dtype == 1) IP(float, bf16raw);
+    else if (src_dtype == 1 && dtype == 1) IP(bf16raw, bf16raw);
+    else if (src_dtype == 1 && dtype == 0) IP(bf16raw, float);
+    else return ERF_EUNSUPPORTED;
+#undef IP
+    return erf_check_launch();
+}

@@ -1,0 +1,266 @@
+// Weight gradients of every convolution as a gather-form MFMA GEMM whose contraction index is
+// the PIXEL:   dW[row][tap*CIN + ci] = sum_p dz[outpix(p)][row] * x[inpix(p, tap)][ci].
+//
+// Per workgroup: a contiguous range of base pixels, walked in steps of 32.  Each step stages
+//   A = dz rows      [32 pixels][COT*16 channels]
+//   B = gathered x   [32 pixels][ntaps*CIN (padded to 16)]
+// in LDS, pixel-major, exactly as they lie in the NHWC tensors.  The MFMA wants its 8 (bf16) /
+// 4 (fp32) K values per lane to be consecutive PIXELS of one channel, i.e. the transpose of that
+// image: bf16 fragments come from ds_read_b64_tr_b16 (hardware 4x16 transpose), fp32 fragments
+// from four strided ds_read_b32.  Accumulators stay in registers over the whole pixel range; each
+// workgroup then writes one fp32 partial tile and a second kernel sums the partials in a fixed
+// order and scatters them into the torch weight layout (no atomics: bit-reproducible).
+#include "common.cuh"
+#include "train.cuh"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgradParams {
+    const void* x;
+    const void* dz;
+    float* partial;
+    int N, Hin, Win, ldx, xoff, Hb, Wb, Hout, Wout, lddz, dzoff, Si, So;
+    int oh, ow, ntaps;
+    int dh[GC_MAX_TAPS], dw[GC_MAX_TAPS];
+    long long P;
+    int steps_per_wg;
+    int ncols_pad;
+};
+
+template <typename T>
+__device__ __forceinline__ i32x4 load_frag(const char* lds, int row_bytes, int col0, int kbase, int lane);
+
+// bf16: pixels kbase + 8q .. +7 of column col0 + (lane & 15)
+template <>
+__device__ __forceinline__ i32x4 load_frag<bf16raw>(const char* lds, int row_bytes, int col0, int kbase, int lane) {
+    const int j = lane & 15, q = lane >> 4;
+    const char* p = lds + (kbase + 8 * q + (j >> 2)) * row_bytes + (col0 + 4 * (j & 3)) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * row_bytes));
+    i32x2 l2 = __builtin_bit_cast(i32x2, lo), h2 = __builtin_bit_cast(i32x2, hi);
+    return i32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+
+// fp32: pixels kbase + 4q .. +3 of column col0 + (lane & 15)
+template <>
+__device__ __forceinline__ i32x4 load_frag<float>(const char* lds, int row_bytes, int col0, int kbase, int lane) {
+    const int j = lane & 15, q = lane >> 4;
+    const char* p = lds + (kbase + 4 * q) * row_bytes + (col0 + j) * 4;
+    i32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = *(const int*)(p + e * row_bytes);
+    return r;
+}
+
+template <typename T, int CIN, int COT, int CPW>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int CH = CIN / EPC;                    // chunks per gathered pixel
+    constexpr int ACH = COT * 16 / EPC;              // chunks per dz pixel
+    constexpr int KPIX = 32;
+    constexpr int SUB = Elem<T>::KSTEP;              // pixels one mma_step consumes (32 bf16, 16 fp32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int a_row = COT * 16 * (int)sizeof(T);
+    const int b_row = p.ncols_pad * (int)sizeof(T);
+    char* a_lds = smem;
+    char* b_lds = smem + KPIX * a_row;
+    __shared__ int s_n[KPIX], s_i[KPIX], s_j[KPIX];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntc = p.ncols_pad >> 4;
+
+    // zero the padding columns of B once
+    const int ncols = p.ntaps * CIN;
+    for (int id = tid; id < KPIX * (p.ncols_pad - ncols); id += 256) {
+        const int px = id / (p.ncols_pad - ncols), c = ncols + id % (p.ncols_pad - ncols);
+        *(T*)(b_lds + px * b_row + c * (int)sizeof(T)) = Elem<T>::from_f32(0.f);
+    }
+
+    f32x4 acc[COT][CPW];
+#pragma unroll
+    for (int r = 0; r < COT; ++r)
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* xg = (const T*)p.x + p.xoff;
+    const T* dzg = (const T*)p.dz + p.dzoff;
+    const long long step0 = (long long)blockIdx.x * p.steps_per_wg;
+
+    for (int s = 0; s < p.steps_per_wg; ++s) {
+        const long long pix0 = (step0 + s) * KPIX;
+        if (pix0 >= p.P) break;
+        __syncthreads();                              // previous step's fragments are consumed
+        if (tid < KPIX) {
+            const long long pix = pix0 + tid;
+            if (pix < p.P) {
+                s_j[tid] = (int)(pix % p.Wb);
+                const long long rest = pix / p.Wb;
+                s_i[tid] = (int)(rest % p.Hb);
+                s_n[tid] = (int)(rest / p.Hb);
+            } else {
+                s_n[tid] = -1; s_i[tid] = 0; s_j[tid] = 0;
+            }
+        }
+        __syncthreads();
+        // A: dz rows of the 32 output pixels
+        for (int id = tid; id < KPIX * ACH; id += 256) {
+            const int px = id / ACH, ch = id % ACH;
+            i32x4 v = {0, 0, 0, 0};
+            const int n = s_n[px];
+            if (n >= 0) {
+                const long long op = ((long long)n * p.Hout + s_i[px] * p.So + p.oh) * p.Wout + s_j[px] * p.So + p.ow;
+                v = *(const i32x4*)(dzg + op * p.lddz + ch * EPC);
+            }
+            *(i32x4*)(a_lds + px * a_row + ch * 16) = v;
+        }
+        // B: gathered input pixels, one CIN-wide column block per tap
+        for (int id = tid; id < p.ntaps * KPIX * CH; id += 256) {
+            const int tap = id / (KPIX * CH), rem = id % (KPIX * CH);
+            const int px = rem / CH, ch = rem % CH;
+            i32x4 v = {0, 0, 0, 0};
+            const int n = s_n[px];
+            if (n >= 0) {
+                const int hi = s_i[px] * p.Si + p.dh[tap], wi = s_j[px] * p.Si + p.dw[tap];
+                if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
+                    v = *(const i32x4*)(xg + (((long long)n * p.Hin + hi) * p.Win + wi) * p.ldx + ch * EPC);
+            }
+            *(i32x4*)(b_lds + px * b_row + (tap * CIN) * (int)sizeof(T) + ch * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < KPIX; kb += SUB) {
+            i32x4 af[COT];
+#pragma unroll
+            for (int r = 0; r < COT; ++r) af[r] = load_frag<T>(a_lds, a_row, r * 16, kb, lane);
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int ct = wave + c * 4;
+                if (ct < ntc) {
+                    const i32x4 bf = load_frag<T>(b_lds, b_row, ct * 16, kb, lane);
+#pragma unroll
+                    for (int r = 0; r < COT; ++r) acc[r][c] = mma_step<T>(af[r], bf, acc[r][c]);
+                }
+            }
+        }
+    }
+
+    // partial tile [COT*16][ncols_pad] of this workgroup
+    float* out = p.partial + (long long)blockIdx.x * (COT * 16) * p.ncols_pad;
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int ct = wave + c * 4;
+        if (ct >= ntc) continue;
+#pragma unroll
+        for (int r = 0; r < COT; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[(long long)(r * 16 + q * 4 + e) * p.ncols_pad + ct * 16 + j] = acc[r][c][e];
+    }
+}
+
+// dW[map(row, tap, ci)] = sum_wg partial[wg][row][tap*CIN + ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int rows_pad,
+                                                           int ncols_pad, int cin, const PackParams m, float* __restrict__ dw) {
+    const int total = m.cout_virtual * m.ntaps * cin;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int col = idx % (m.ntaps * cin), row = idx / (m.ntaps * cin);
+    const int tap = col / cin, ci = col % cin;
+    const int phase = row / m.ncp, cls = row % m.ncp;
+    if (cls >= m.nc_valid || (m.cin_valid && ci >= m.cin_valid)) return;
+    double s = 0;
+    const long long stride = (long long)rows_pad * ncols_pad;
+    const float* src = partial + (long long)row * ncols_pad + col;
+    for (int g = 0; g < nwg; ++g) s += src[g * stride];
+    dw[(long long)cls * m.s_co + (long long)phase * m.s_phase + (long long)ci * m.s_ci + m.toff[tap]] = (float)s;
+}
+
+static void plan(long long P, int* nwg, int* spw) {
+    const long long steps = (P + 31) / 32;
+    long long s = (steps + 255) / 256;
+    if (s < 8) s = 8;
+    *spw = (int)s;
+    *nwg = (int)((steps + s - 1) / s);
+}
+
+size_t wgrad_workspace_bytes(int rows, int cin, int max_taps_per_phase, long long base_pixels) {
+    int nwg, spw;
+    plan(base_pixels, &nwg, &spw);
+    const int rows_pad = (rows + 15) / 16 * 16;
+    const int ncols_pad = (max_taps_per_phase * cin + 15) / 16 * 16;
+    return (size_t)nwg * rows_pad * ncols_pad * sizeof(float);
+}
+
+template <typename T, int CIN, int COT, int CPW>
+static int launch_phase(const WgradParams& wp, int nwg, hipStream_t stream) {
+    if constexpr (CIN % Elem<T>::EPC != 0) {
+        return ERF_EUNSUPPORTED;
+    } else {
+    const size_t lds = (size_t)32 * (COT * 16 + wp.ncols_pad) * sizeof(T);
+    auto kern = wgrad_kernel<T, CIN, COT, CPW>;
+    if (lds > 64 * 1024) {
+        if (lds > 150 * 1024) return ERF_EUNSUPPORTED;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ERF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, wp);
+    return erf_check_launch();
+    }
+}
+
+#define WG_CASE(CINV, COTV, CPWV)                                                                         \
+    if (cin == CINV && cot == COTV && cpw <= CPWV)                                                        \
+        return dtype == 1 ? launch_phase<bf16raw, CINV, COTV, CPWV>(wp, nwg, stream)                      \
+                          : launch_phase<float, CINV, COTV, CPWV>(wp, nwg, stream);
+
+static int dispatch(const WgradParams& wp, int dtype, int cin, int cot, int cpw, int nwg, hipStream_t stream) {
+    WG_CASE(16, 1, 1)       // conv1d C=16 (3 col tiles)
+    WG_CASE(64, 4, 3)       // conv1d C=64 (12 col tiles)
+    WG_CASE(128, 8, 6)      // conv1d C=128 (24 col tiles)
+    WG_CASE(16, 3, 3)       // downsampler 16->64 (9 col tiles)
+    WG_CASE(64, 4, 9)       // downsampler 64->128 (36 col tiles)
+    WG_CASE(128, 4, 8)      // upsampler 128->64 (<= 32 col tiles per phase)
+    WG_CASE(64, 1, 4)       // upsampler 64->16 (<= 16 col tiles per phase)
+    WG_CASE(16, 2, 1)       // output_conv, nc <= 8
+    WG_CASE(16, 5, 1)       // output_conv, nc <= 20
+    WG_CASE(16, 8, 1)       // output_conv, nc <= 32
+    WG_CASE(8, 1, 2)        // stem, bf16 image padded to 8 channels (5 col tiles)
+    WG_CASE(4, 1, 1)        // stem, fp32 image padded to 4 channels (3 col tiles)
+    WG_CASE(128, 1, 2)      // encoder output_conv 1x1, nc <= 16
+    WG_CASE(128, 2, 2)      // encoder output_conv 1x1, nc <= 32
+    return ERF_EUNSUPPORTED;
+}
+
+int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, int rows, int cin, const PackParams* maps,
+                 float* dw, float* workspace, size_t workspace_bytes, int dtype, hipStream_t stream) {
+    const long long P = (long long)geo.N * geo.Hb * geo.Wb;
+    int nwg, spw;
+    plan(P, &nwg, &spw);
+    const int cot = (rows + 15) / 16;
+    const int epc = dtype == 1 ? 8 : 4;
+    if (cin % epc) return ERF_EUNSUPPORTED;
+    for (int ph = 0; ph < geo.nphase; ++ph) {
+        const GConvPhase& g = geo.ph[ph];
+        WgradParams wp{};
+        wp.x = geo.x; wp.dz = dz; wp.partial = workspace;
+        wp.N = geo.N; wp.Hin = geo.Hin; wp.Win = geo.Win; wp.ldx = geo.ldx; wp.xoff = geo.xoff; wp.Hb = geo.Hb; wp.Wb = geo.Wb;
+        wp.Hout = geo.Hout; wp.Wout = geo.Wout; wp.lddz = lddz; wp.dzoff = dzoff; wp.Si = geo.Si; wp.So = geo.So;
+        wp.oh = g.oh; wp.ow = g.ow; wp.ntaps = g.ntaps;
+        for (int t = 0; t < g.ntaps; ++t) { wp.dh[t] = g.dh[t]; wp.dw[t] = g.dw[t]; }
+        wp.P = P; wp.steps_per_wg = spw;
+        wp.ncols_pad = (g.ntaps * cin + 15) / 16 * 16;
+        const size_t need = (size_t)nwg * cot * 16 * wp.ncols_pad * sizeof(float);
+        if (need > workspace_bytes) return ERF_EINVAL;
+        const int cpw = (wp.ncols_pad / 16 + 3) / 4;
+        int rc = dispatch(wp, dtype, cin, cot, cpw, nwg, stream);
+        if (rc) return rc;
+        const PackParams& m = maps[ph];
+        const int total = m.cout_virtual * m.ntaps * cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, workspace, nwg, cot * 16,
+                           wp.ncols_pad, cin, m, dw);
+        rc = erf_check_launch();
+        if (rc) return rc;
+    }
+    return ERF_OK;
+}

@@ -1,0 +1,78 @@
+"""Weighted 2-D cross entropy on the GPU kernels.
+
+`CrossEntropyLoss2d(weight)` has the interface of /root/reference/train/main.py:72-80 and
+computes what `torch.nn.CrossEntropyLoss(weight)` computes at train/main.py:121,202:
+
+    L = sum_p w[t_p] * (-log softmax(z_p)[t_p]) / sum_p w[t_p]
+
+Numerator and denominator are produced separately (erf_weighted_ce_fwd).  With `group` set, both
+are all-reduced over the process group before the division, which reproduces nn.DataParallel's
+loss over the gathered global batch (per-rank means would weight the shards unequally); the
+backward pass then scales every rank's dlogits by 1/global-denominator, so summing the ranks'
+parameter gradients gives the global-batch gradient.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import call, query
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _WeightedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, group):
+        ops.require_gpu(logits, "CrossEntropyLoss2d")
+        logits = logits.contiguous()
+        target = target.contiguous()
+        if target.dtype != torch.int64:
+            raise TypeError("targets must be int64 class indices")
+        n, c, h, w = logits.shape
+        if target.shape != (n, h, w):
+            raise ValueError(f"expected target of shape {(n, h, w)}, got {tuple(target.shape)}")
+        dev = logits.device
+        wt = None if weight is None else weight.detach().to(dev, torch.float32).contiguous()
+        out3 = torch.empty(3, device=dev)
+        ws = torch.empty(query("erf_ce_workspace_bytes"), dtype=torch.uint8, device=dev)
+        call("erf_weighted_ce_fwd", logits.data_ptr(), ops.dt(logits), target.data_ptr(), 0 if wt is None else wt.data_ptr(),
+             n, c, h * w, out3.data_ptr(), ws.data_ptr(), _stream())
+        if group is not None:
+            import torch.distributed as dist
+            parts = out3[:2].clone()
+            dist.all_reduce(parts, group=group)
+            num, den = parts[0], parts[1]
+        else:
+            num, den = out3[0], out3[1]
+        ctx.save_for_backward(logits, target, den.reshape(1))
+        ctx.weight = wt
+        return num / den
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, den = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        coef = (gout.reshape(1).float() / den).contiguous()
+        dlogits = torch.empty_like(logits)
+        wt = ctx.weight
+        call("erf_weighted_ce_bwd", logits.data_ptr(), ops.dt(logits), target.data_ptr(), 0 if wt is None else wt.data_ptr(),
+             n, c, h * w, coef.data_ptr(), dlogits.data_ptr(), _stream())
+        return dlogits, None, None, None
+
+
+def weighted_cross_entropy(logits, target, weight=None, group=None):
+    return _WeightedCE.apply(logits, target, weight, group)
+
+
+class CrossEntropyLoss2d(torch.nn.Module):
+
+    def __init__(self, weight=None, group=None):
+        super().__init__()
+        self.register_buffer("weight", None if weight is None else torch.as_tensor(weight, dtype=torch.float32))
+        self.group = group
+
+    def forward(self, outputs, targets):
+        return weighted_cross_entropy(outputs, targets, self.weight, self.group)

@@ -111,6 +111,108 @@ int erf_argmax_c(const void* logits, int dtype, void* labels, int label_bytes, i
 int erf_iou_hist_accumulate(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count,
                             int nc, long long* hist, void* stream);
 
+/* =========================== training step =============================================== */
+
+/* ---- BatchNorm2d(C, eps=1e-3) in training mode, train/erfnet.py:17,47,53,150 ------------
+ * erf_bn_stats_finalize: per-channel batch mean / biased variance of z (NHWC, `pixels` = N*H*W),
+ *   mean/invstd for the backward pass, the folded affine scale = gamma*invstd,
+ *   shift = beta - mean*scale, and the running-statistics update
+ *   running = (1-momentum)*running + momentum*(mean, unbiased var) (skipped when running_mean NULL).
+ * erf_bn_apply: y = act(((z - center)*scale + shift) * mask[n][c] + residual).  With center = mean,
+ *   scale = gamma*invstd, shift = beta this is torch's (z - mean)*invstd*gamma + beta without the
+ *   cancellation of the folded form; center NULL means 0.  mask (Dropout2d multipliers [N][C],
+ *   train/erfnet.py:71-72) and residual (:74) may be NULL.
+ * erf_bn_backward: with dy = g * [gate > 0] * mask (ReLU and Dropout2d backward folded in; gate and
+ *   mask may be NULL): dgamma = sum dy*xhat, dbeta = sum dy,
+ *   dz = gamma*invstd*(dy - dbeta/M - xhat*dgamma/M)  (batch_stats = 1), or gamma*invstd*dy (= 0,
+ *   eval-mode statistics).  g_out (may be NULL) receives g * [gate > 0], the gradient that flows into
+ *   the residual branch.
+ * workspace: erf_bn_workspace_bytes(C) bytes, contents undefined on entry. */
+size_t erf_bn_workspace_bytes(int C);
+int erf_bn_stats_finalize(const void* z, int dtype, long long pixels, int C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                          float* scale, float* shift, void* workspace, void* stream);
+int erf_bn_apply(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* residual,
+                 const float* mask, int dtype, int N, long long HW, int C, int relu, void* stream);
+int erf_bn_backward(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
+                    const float* invstd, const float* gamma, int batch_stats, void* dz, void* g_out, float* dgamma,
+                    float* dbeta, int dtype, int N, long long HW, int C, void* workspace, void* stream);
+/* out = g * [gate > 0]: F.relu backward between the two convs of a factorized pair (train/erfnet.py:61,67). */
+int erf_relu_backward(const void* g, const void* gate, void* out, int dtype, long long count, void* stream);
+/* sums[c] = sum_p z[p][c]: conv bias gradients.  workspace as for BatchNorm. */
+int erf_channel_sum(const void* z, int dtype, long long pixels, int C, float* sums, void* workspace, void* stream);
+/* nn.Dropout2d(p) multipliers (train/erfnet.py:55): mask[i] = Bernoulli(1-p)/(1-p), i < count = N*C,
+ * a counter-based hash of (seed, i). */
+int erf_dropout2d_mask(float* mask, int count, float p, unsigned long long seed, void* stream);
+/* MaxPool2d(2, stride 2) backward of the DownsamplerBlock (train/erfnet.py:16,20): routes
+ * dz[..., zoff:zoff+Cin] (channel stride ldz) to the first maximum of each window of x;
+ * accumulate != 0 adds to dx (after the conv part's data gradient), else overwrites. */
+int erf_maxpool2x2_backward(const void* x, const void* dz, void* dx, int dtype, int N, int Hin, int Win, int Cin, int ldz,
+                            int zoff, int accumulate, void* stream);
+
+/* ---- loss: torch.nn.CrossEntropyLoss(weight), train/main.py:121,202 (= CrossEntropyLoss2d :72-80)
+ * fwd: out3 = { sum_p w[t_p]*nll_p, sum_p w[t_p], their quotient }; targets outside [0,C) count as
+ *   ignored.  The two sums are returned separately so that data-parallel ranks can divide by the
+ *   GLOBAL denominator, as DataParallel's loss over the gathered batch does.
+ * bwd: dlogits = coef[0] * w[t] * (softmax - onehot), coef a DEVICE scalar (grad_output / denominator).
+ * logits / dlogits NCHW of `dtype`; target int64 [N,H,W]; weight fp32 [C] or NULL. */
+size_t erf_ce_workspace_bytes(void);
+int erf_weighted_ce_fwd(const void* logits, int dtype, const long long* target, const float* weight, int N, int C,
+                        long long HW, float* out3, void* workspace, void* stream);
+int erf_weighted_ce_bwd(const void* logits, int dtype, const long long* target, const float* weight, int N, int C,
+                        long long HW, const float* coef, void* dlogits, void* stream);
+
+/* ---- optimiser: torch.optim.Adam(lr, betas, eps, weight_decay) of train/main.py:140 and
+ * torch.optim.SGD(lr, momentum, weight_decay) of imagenet/main.py:83-85, over flat fp32 arenas.
+ * g = grad * grad_scale + weight_decay * p (coupled L2); step is 1-based.  Hyper-parameters are
+ * doubles (as Python floats are): 1 - beta and the bias corrections are formed in double first. */
+int erf_adam_fused_arena(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
+int erf_sgd_fused_arena(float* params, const float* grads, float* momentum_buf, long long n, double lr, double momentum,
+                        double weight_decay, int first_step, double grad_scale, void* stream);
+
+/* ---- data gradients (autograd of the layers above) --------------------------------------
+ * conv1d: dx = conv1d(dy; erf_conv1d_pack(mode 1)) * [gate > 0] + residual (gate, residual may be NULL).
+ * downsampler: dx = convT(dz[..., :Cout-Cin]) (pool part: erf_maxpool2x2_backward with accumulate).
+ * upsampler: dx = conv3x3 s2 (dz) * [gate > 0].
+ * output_conv: dlogits NCHW -> patches [N,Hin,Win,ldp] with channel 4*class + (2a+b), ldp =
+ *   erf_output_conv_patch_channels(nc); dx = patches x W^T * [gate > 0]. */
+int erf_conv1d_dgrad(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual, int dtype,
+                     int N, int H, int W, int C, int axis, int dilation, void* stream);
+size_t erf_downsampler_dgrad_packed_bytes(int dtype, int Cin, int Cout);
+int erf_downsampler_dgrad_pack(const float* w, void* packed, int dtype, int Cin, int Cout, void* stream);
+int erf_downsampler_dgrad(const void* dz, void* dx, const void* packed_t, int dtype, int N, int Hin, int Win, int Cin,
+                          int Cout, void* stream);
+size_t erf_upsampler_dgrad_packed_bytes(int dtype, int Cin, int Cout);
+int erf_upsampler_dgrad_pack(const float* w, void* packed, int dtype, int Cin, int Cout, void* stream);
+int erf_upsampler_dgrad(const void* dz, void* dx, const void* packed_t, const void* gate, int dtype, int N, int Hin, int Win,
+                        int Cin, int Cout, void* stream);
+int erf_output_conv_patch_channels(int nc);
+int erf_output_conv_patches(const void* dlogits, int src_dtype, void* patches, int dtype, int N, int Hin, int Win, int nc,
+                            void* stream);
+size_t erf_output_conv_dgrad_packed_bytes(int dtype, int nc);
+int erf_output_conv_dgrad_pack(const float* w, void* packed, int dtype, int nc, void* stream);
+int erf_output_conv_dgrad(const void* patches, void* dx, const void* packed_t, const void* gate, int dtype, int N, int Hin,
+                          int Win, int nc, void* stream);
+
+/* ---- weight gradients: dW in the parameter's own torch layout, fp32, overwritten -----------
+ * Contraction over pixels on MFMA tiles; per-workgroup partial tiles in `workspace`
+ * (erf_wgrad_workspace_bytes(rows = output channels, cin, taps per phase, base pixels)), summed in a
+ * fixed order.  x = the layer's forward input, dz = gradient at its (pre-BatchNorm) output.
+ * Stem: x_pad from erf_image_to_nhwc_padded (image as NHWC, channels zero-padded to 8 bf16 / 4 fp32). */
+size_t erf_wgrad_workspace_bytes(int rows, int cin, int taps_per_phase, long long base_pixels);
+int erf_conv1d_wgrad(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis, int dilation,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int erf_downsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, int N, int Hin, int Win, int Cin, int Cout,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int erf_image_to_nhwc_padded(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, void* stream);
+int erf_stem_wgrad(const void* x_pad, const void* dz, float* dw, int dtype, int N, int Hin, int Win, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int erf_upsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, int N, int Hin, int Win, int Cin, int Cout,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int erf_output_conv_wgrad(const void* x, const void* patches, float* dw, int dtype, int N, int Hin, int Win, int nc,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

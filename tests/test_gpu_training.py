@@ -1,0 +1,328 @@
+"""GPU parity of the training path (autograd Functions -> C ABI -> gfx950 kernels) against the
+golden vectors produced by the reference's modules in training mode and against the CPU oracle.
+
+fp32 bar: 1e-4 relative to each tensor's max magnitude (north-star).  bf16: 4e-2 on block
+outputs / input gradients, 6e-2 on parameter gradients (bf16 activations and saved tensors).
+Gradients of conv biases that feed a training-mode BatchNorm are mathematically zero; they are
+judged on an absolute scale (`floor`), see tests/golden_util.pre_bn_bias.
+"""
+import numpy as np
+import pytest
+import torch
+
+from erfnet_pytorch_amd import synthetic as S
+from oracle import erfnet_oracle as O
+from tests.golden_util import load, check_packed, activations, upstream, rel_err, pre_bn_bias, gate_tolerant_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _block_tags():
+    g = load("g2_blocks.npz")
+    return sorted({k.split("__prefix")[0] for k in g.files if k.endswith("__prefix")})
+
+
+def _make_block(tag, g):
+    from erfnet_pytorch_amd import erfnet as E
+    prefix = str(g[tag + "__prefix"])
+    shape = tuple(int(v) for v in g[tag + "__xshape"])
+    seed = int(g[tag + "__seed"])
+    kind = tag.split("_")[0]
+    if kind == "nb":
+        c, d, p = int(tag.split("_")[1][1:]), int(tag.split("_")[2][1:]), int(tag.split("_")[3][1:]) / 100.0
+        mod, tmpl, x = E.non_bottleneck_1d(c, p, d), O.nb_template(prefix, c), activations(shape, seed)
+    elif kind == "down":
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        mod, tmpl = E.DownsamplerBlock(cin, cout), O.down_template(prefix, cin, cout)
+        x = S.synthetic_images(shape[0], shape[2], shape[3], seed=seed) if cin == 3 else activations(shape, seed)
+    else:
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        mod, tmpl, x = E.UpsamplerBlock(cin, cout), O.up_template(prefix, cin, cout), activations(shape, seed)
+    sd = O.synthetic_state(tmpl)
+    mod.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items()})
+    return mod.to(DEV), x, seed
+
+
+def _oracle_block(tag, g, x, seed):
+    """Reference tensors from the CPU oracle (itself pinned by the golden vectors) for input x."""
+    prefix = str(g[tag + "__prefix"])
+    kind = tag.split("_")[0]
+    if kind == "nb":
+        c, d, p = int(tag.split("_")[1][1:]), int(tag.split("_")[2][1:]), int(tag.split("_")[3][1:]) / 100.0
+        tmpl, fwd = O.nb_template(prefix, c), (lambda sd, xx, st: O.nb1d(sd, prefix, xx, d, p, st))
+    elif kind == "down":
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        tmpl, fwd = O.down_template(prefix, cin, cout), (lambda sd, xx, st: O.downsampler(sd, prefix, xx, st))
+    else:
+        cin, cout = int(tag.split("_")[1]), int(tag.split("_")[2])
+        tmpl, fwd = O.up_template(prefix, cin, cout), (lambda sd, xx, st: O.upsampler(sd, prefix, xx, st))
+    sd = O.synthetic_state(tmpl)
+    leaf = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v)
+            for k, v in sd.items()}
+    masks = {prefix: torch.from_numpy(g[tag + "_mask"])} if (tag + "_mask") in g.files else {}
+    st = O.RunState(training=True, dropout_masks=masks)
+    xr = x.clone().requires_grad_(True)
+    y = fwd(leaf, xr, st)
+    y.backward(upstream(tuple(y.shape), seed))
+    grads = {k[len(prefix) + 1:]: v.grad for k, v in leaf.items() if v.requires_grad}
+    bufs = {k[len(prefix) + 1:]: v for k, v in st.new_running.items()}
+    return y.detach(), xr.grad, grads, bufs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", _block_tags())
+def test_block_train_forward_backward(tag, dtype):
+    """fp32: against the golden vectors of the reference.  bf16: against the oracle evaluated on the
+    bf16-rounded input (max-pool routing and ReLU gates depend on the rounded values)."""
+    g = load("g2_blocks.npz")
+    mod, x, seed = _make_block(tag, g)
+    mod.train()
+    if (tag + "_mask") in g.files:
+        mod.__dict__["_erf_forced_mask"] = torch.from_numpy(g[tag + "_mask"])
+    is_stem = tag.startswith("down_3_")
+    bf16 = dtype == torch.bfloat16
+    tol, ptol = (4e-2, 6e-2) if bf16 else (1e-4, 1e-4)
+    if bf16 and not is_stem:
+        x = x.bfloat16().float()
+    xg = x.to(DEV, dtype if not is_stem else torch.float32).requires_grad_(not is_stem)
+    if is_stem and bf16:
+        mod.__dict__["_erf_code"] = 1
+    y = mod(xg)
+    y.backward(upstream(tuple(y.shape), seed).to(DEV, y.dtype))
+    torch.cuda.synchronize()
+    if bf16:
+        # forward: continuous in the inputs -> max-norm bound.  gradients: ReLU gates (and max-pool
+        # routes) of values within bf16 rounding of a tie flip freely, see gate_tolerant_err.
+        ry, rdx, rgrads, rbufs = _oracle_block(tag, g, x, seed)
+        assert rel_err(y.float().cpu(), ry) <= tol
+        if not is_stem:
+            q, l2 = gate_tolerant_err(xg.grad.float().cpu(), rdx, 0.10)
+            assert q <= 6e-2 and l2 <= 0.3, ("dx", q, l2)
+        for k, p in mod.named_parameters():
+            assert p.grad.dtype == torch.float32 and p.grad.shape == p.shape, k
+            q, l2 = gate_tolerant_err(p.grad.cpu(), rgrads[k], 0.10, 30.0 if pre_bn_bias(k) else 0.0)
+            assert q <= 0.15 and l2 <= 0.3, (k, q, l2)
+        for k, b in mod.named_buffers():
+            if "num_batches" not in k:
+                assert rel_err(b.cpu(), rbufs[k]) <= 2e-2, k
+        return
+    check_packed(g, tag + "_y_train", y.float().cpu(), tol)
+    if not is_stem:
+        check_packed(g, tag + "_dx", xg.grad.float().cpu(), tol, outlier_frac=0.02, l2tol=3e-2)
+    for k, p in mod.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape, k
+        check_packed(g, tag + "_grad_" + k, p.grad.cpu(), ptol, floor=30.0 if pre_bn_bias(k) else 0.0, outlier_frac=0.02,
+                     l2tol=3e-2)
+    for k, b in mod.named_buffers():
+        if "num_batches" in k:
+            assert int(b) == 1
+        else:
+            check_packed(g, tag + "_buf_" + k, b.cpu(), 1e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("c,shape,axis,dil", [(64, (2, 64, 24, 40), 0, 1), (64, (2, 64, 24, 40), 1, 1), (128, (1, 128, 40, 40), 0, 16),
+                                              (128, (1, 128, 40, 40), 1, 8), (128, (2, 128, 16, 24), 1, 2), (16, (2, 16, 24, 48), 1, 1),
+                                              (16, (2, 16, 24, 48), 0, 1)])
+def test_conv1d_dgrad_wgrad_primitives(dtype, tol, c, shape, axis, dil):
+    """Gate-free check of the two backward GEMMs against torch-CPU autograd on identical (pre-rounded)
+    operands; the gate and residual of the dgrad epilogue are explicit inputs here."""
+    import torch.nn.functional as F
+    from erfnet_pytorch_amd import ops, autograd as ag
+    seed = 300 + c + axis + dil
+    rnd = lambda t: t.to(dtype).float()
+    x = rnd(activations(shape, seed) - 0.3)
+    dy = rnd(upstream(shape, seed))
+    gate = activations(shape, seed + 1) - 0.4
+    res = rnd(upstream(shape, seed + 2))
+    kshape = (c, c, 3, 1) if axis == 0 else (c, c, 1, 3)
+    w = S.fill_tensor("t.conv.weight", kshape, salt=seed)
+    wr = rnd(w).requires_grad_(True)
+    pad, dl = ((dil, 0), (dil, 1)) if axis == 0 else ((0, dil), (1, dil))
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=pad, dilation=dl).backward(dy)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    code = ops.dt(torch.empty(0, dtype=dtype))
+    dx = ag.conv1d_dgrad(nh(dy), ops.pack_conv1d(w.to(DEV), code, 1), nh(gate), nh(res), axis, dil)
+    ref = xr.grad * (rnd(gate) > 0) + res
+    assert rel_err(dx.float().cpu().permute(0, 3, 1, 2), ref) <= tol
+    dw = ag.conv1d_wgrad(nh(x), nh(dy), w.shape, axis, dil)
+    assert rel_err(dw.cpu(), wr.grad) <= (1e-5 if dtype == torch.float32 else 1e-5)      # operands identical: fp32 sums
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
+def test_batchnorm_primitives(dtype, tol):
+    import torch.nn.functional as F
+    from erfnet_pytorch_amd import autograd as ag
+    n, c, h, w = 2, 64, 24, 40
+    rnd = lambda t: t.to(dtype).float()
+    z = rnd(upstream((n, c, h, w), 7) * 1.5 + 0.3)
+    res = rnd(upstream((n, c, h, w), 8))
+    gup = rnd(upstream((n, c, h, w), 9))
+    mask = (S.fill_tensor("m.weight", (n * c,), 5).reshape(n, c) > 1.1).float() / 0.7
+    bn = torch.nn.BatchNorm2d(c, eps=1e-3)
+    bn.load_state_dict({k: S.fill_tensor("b.bn." + k, v.shape) for k, v in bn.state_dict().items()})
+    bn2 = torch.nn.BatchNorm2d(c, eps=1e-3)
+    bn2.load_state_dict(bn.state_dict())
+    bn2 = bn2.to(DEV)
+    zr = z.clone().requires_grad_(True)
+    out = F.relu(bn(zr) * mask[:, :, None, None] + res)
+    out.backward(gup)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    back = lambda t: t.float().cpu().permute(0, 3, 1, 2)
+    zh = nh(z)
+    mean, invstd, s, t = ag.bn_forward_stats(zh, bn2, True)
+    o = ag.bn_apply(zh, mean, s, t, residual=nh(res), mask=mask.to(DEV))
+    assert rel_err(back(o), out) <= tol
+    # gate with the REFERENCE's output so that no ReLU gate can differ
+    dz, g_out, dg, db = ag.bn_backward(nh(gup), nh(out.detach()), mask.to(DEV), zh, mean, invstd, bn2.weight.detach(), True, True)
+    assert rel_err(back(dz), zr.grad) <= tol
+    assert rel_err(dg.cpu(), bn.weight.grad) <= 1e-5 and rel_err(db.cpu(), bn.bias.grad) <= 1e-5
+    assert rel_err(bn2.running_mean.cpu(), bn.running_mean) <= 1e-6 and rel_err(bn2.running_var.cpu(), bn.running_var) <= 1e-6
+    assert torch.equal(back(g_out), gup * (out > 0))
+
+
+@pytest.mark.parametrize("nc", [20, 6])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+def test_output_conv_backward(nc, dtype, tol):
+    from erfnet_pytorch_amd import autograd as ag
+    g = load("g2_blocks.npz")
+    tag = f"outconv_{nc}"
+    seed = int(g[tag + "__seed"])
+    w = S.fill_tensor("decoder.output_conv.weight", (16, nc, 2, 2), salt=seed).to(DEV).requires_grad_(True)
+    b = S.fill_tensor("decoder.output_conv.bias", (nc,), salt=seed).to(DEV).requires_grad_(True)
+    x = activations((2, 16, 12, 16), seed).to(DEV, dtype).requires_grad_(True)
+    y = ag._OutConvFn.apply(x, w, b, True)
+    assert y.dtype == torch.float32 and y.is_contiguous()
+    y.backward(upstream(tuple(y.shape), seed).to(DEV))
+    check_packed(g, tag + "_y", y.cpu(), tol)
+    check_packed(g, tag + "_dx", x.grad.float().cpu(), tol)
+    check_packed(g, tag + "_grad_weight", w.grad.cpu(), tol)
+    check_packed(g, tag + "_grad_bias", b.grad.cpu(), tol)
+
+
+def test_weighted_ce_forward_backward():
+    from erfnet_pytorch_amd.loss import CrossEntropyLoss2d
+    g = load("g3_loss.npz")
+    crit = CrossEntropyLoss2d(torch.tensor(O.CITYSCAPES_WEIGHTS)).to(DEV)
+    for tag in ("mixed", "ignored"):
+        n, h, wd, seed, all_ign = (int(v) for v in g[tag + "__in"])
+        z = (3.0 * upstream((n, 20, h, wd), seed)).to(DEV).requires_grad_(True)
+        t = S.synthetic_labels(n, h, wd, 20, seed=seed)[:, 0]
+        if all_ign:
+            t = torch.full_like(t, 19)
+        loss = crit(z, t.to(DEV))
+        loss.backward()
+        gold = float(g[tag + "_loss"])
+        if all_ign:
+            assert np.isnan(gold) and torch.isnan(loss).item()        # 0/0, as torch
+        else:
+            assert abs(loss.item() - gold) <= 2e-6 * abs(gold)
+            check_packed(g, tag + "_dlogits", z.grad.cpu(), 1e-5)
+    crit = CrossEntropyLoss2d(None).to(DEV)                            # unweighted, class logits as a 1x1 map
+    z = (2.0 * upstream((8, 1000), 33)).to(DEV).reshape(8, 1000, 1, 1).requires_grad_(True)
+    t = S.synthetic_labels(8, 1, 1, 1000, seed=33, ignore_frac=0)[:, 0, 0, 0].reshape(8, 1, 1).to(DEV)
+    loss = crit(z, t)
+    loss.backward()
+    assert abs(loss.item() - float(g["cls_loss"])) <= 2e-6 * abs(float(g["cls_loss"]))
+    check_packed(g, "cls_dlogits", z.grad.reshape(8, 1000).cpu(), 1e-5)
+
+
+def test_full_train_step_fp32_vs_golden():
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.loss import CrossEntropyLoss2d
+    g = load("g5_train_steps.npz")
+    sd = O.synthetic_state(O.erfnet_template(20))
+    model = E.ERFNet(20)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    for name, mod in model.named_modules():
+        key = f"s0_mask_{name}"
+        if key in g.files:
+            mod.__dict__["_erf_forced_mask"] = torch.from_numpy(g[key])
+    crit = CrossEntropyLoss2d(torch.tensor(O.CITYSCAPES_WEIGHTS)).to(DEV)
+    x = S.synthetic_images(2, 64, 128, seed=50).to(DEV)
+    t = S.synthetic_labels(2, 64, 128, 20, seed=50)[:, 0].to(DEV)
+    y = model(x)
+    loss = crit(y, t)
+    loss.backward()
+    gold = float(g["s0_loss"])
+    assert abs(loss.item() - gold) <= 1e-4 * abs(gold), (loss.item(), gold)
+    # Training-mode logits pass through 39 BatchNorms whose batch statistics come from as few as 256
+    # samples here (2 x 8 x 16 maps), so fp32 rounding is amplified by each 1/std: the REFERENCE's own
+    # fp32 result sits 8.5e-5 (max) / 7.4e-5 (L2) away from the same graph evaluated in fp64.  Two
+    # independent fp32 evaluations therefore differ by up to ~2e-4.  Bars: within 1.5e-4 (max and L2) of
+    # the fp64 evaluation of the oracle (measured 1.0e-4 / 1.0e-4, i.e. 1.2x - 1.4x the reference's own fp32
+    # error), and within 3e-4 of the reference's fp32 golden logits.
+    ref = torch.from_numpy(g["s0_logits__sample"])
+    got = y.detach().cpu().reshape(-1)[:: int(g["s0_logits__stride"])]
+    assert rel_err(got, ref) <= 3e-4, rel_err(got, ref)
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    m64 = {str(k): torch.from_numpy(g[f"s0_mask_{k}"]).double() for k in g["s0_masks__keys"]}
+    with torch.no_grad():
+        y64 = O.erfnet(sd64, S.synthetic_images(2, 64, 128, seed=50).double(),
+                       O.RunState(training=True, dropout_masks=m64, update_running=False))
+    assert rel_err(y.detach().cpu(), y64) <= 1.5e-4, rel_err(y.detach().cpu(), y64)
+    assert gate_tolerant_err(y.detach().cpu(), y64, 0.0)[1] <= 1.5e-4
+    names = [str(s) for s in g["param_names"]]
+    gn = g["s0_gradnorm"]
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for i, k in enumerate(names):
+        p = params[k]
+        if gn[i] < 0:
+            assert p.grad is None                         # encoder.output_conv is unused by the full forward
+            continue
+        mine = p.grad.double().norm().item()
+        if pre_bn_bias(k):
+            assert mine < 2e-3 and gn[i] < 2e-3
+            continue
+        worst = max(worst, abs(mine - gn[i]) / max(gn[i], 1e-6))
+    assert worst <= 2e-2, worst            # norms absorb the occasional flipped ReLU gate (see gate_tolerant_err)
+    for key in [f for f in g.files if f.startswith("s0_grad_") and f.endswith("__shape")]:
+        k = key[len("s0_grad_"):-len("__shape")]
+        # End-to-end gradients of this 74-conv / 39-BatchNorm graph on 2 x 64 x 128 inputs are ill-conditioned:
+        # the reference's own fp32 gradients differ from an fp64 evaluation of the same graph by 7.5e-3
+        # (median over tensors, max-norm).  The per-block tests above hold the 1e-4 bar; here 3e-2.
+        check_packed(g, "s0_grad_" + k, params[k].grad.cpu(), 3e-2, floor=30.0 if pre_bn_bias(k) else 0.0, outlier_frac=0.02,
+                     l2tol=5e-2)
+
+
+def test_adam_and_sgd_kernels_vs_oracle():
+    from erfnet_pytorch_amd._lib import call
+    n = 100003
+    gen = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=gen)
+    p_ref, m_ref, v_ref = p0.clone(), torch.zeros(n), torch.zeros(n)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=gen) * 0.1
+        O.adam_step([p_ref], [grad], [m_ref], [v_ref], step, lr=5e-4, weight_decay=1e-4)
+        gd = grad.to(DEV)
+        call("erf_adam_fused_arena", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 5e-4, 0.9, 0.999, 1e-8, 1e-4,
+             step, 1.0, st)
+        assert rel_err(p.cpu(), p_ref) < 1e-6 and rel_err(m.cpu(), m_ref) < 1e-6 and rel_err(v.cpu(), v_ref) < 1e-6
+    p_ref, bufs = p0.clone(), [None]
+    p, buf = p0.to(DEV), torch.zeros(n, device=DEV)
+    for step in range(3):
+        grad = torch.randn(n, generator=gen) * 0.1
+        O.sgd_step([p_ref], [grad], bufs)
+        call("erf_sgd_fused_arena", p.data_ptr(), grad.to(DEV).data_ptr(), buf.data_ptr(), n, 0.1, 0.9, 1e-4, int(step == 0),
+             1.0, st)
+        assert rel_err(p.cpu(), p_ref) < 1e-6
+
+
+def test_dropout_mask_statistics():
+    from erfnet_pytorch_amd import autograd as ag
+    for p in (0.03, 0.3):
+        torch.manual_seed(11)
+        m = ag.dropout_mask(64, 128, p, torch.device(DEV)).cpu()
+        keep = 1.0 / (1.0 - p)
+        assert bool(((m == 0) | ((m - keep).abs() < 1e-6)).all())
+        frac = (m == 0).float().mean().item()
+        sigma = (p * (1 - p) / m.numel()) ** 0.5
+        assert abs(frac - p) < 5 * sigma, (frac, p)
+        m2 = ag.dropout_mask(64, 128, p, torch.device(DEV)).cpu()
+        assert not torch.equal(m, m2)                     # a fresh mask per call
