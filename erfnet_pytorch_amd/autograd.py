@@ -68,13 +68,13 @@ def bn_apply(z, center, scale, shift, residual=None, mask=None, relu=True):
     return y
 
 
-def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=False):
+def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=False, dgamma=None, dbeta=None):
     n, h, w, c = z.shape
     dev = z.device
     dz = torch.empty_like(z)
     g_out = torch.empty_like(z) if want_g_out else None
-    dgamma = torch.empty(c, device=dev)
-    dbeta = torch.empty(c, device=dev)
+    dgamma = torch.empty(c, device=dev) if dgamma is None else dgamma
+    dbeta = torch.empty(c, device=dev) if dbeta is None else dbeta
     ws = _ws(query("erf_bn_workspace_bytes", c), dev)
     call("erf_bn_backward", g.data_ptr(), _p(gate), _p(mask), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
          gamma.data_ptr(), int(batch_stats), dz.data_ptr(), _p(g_out), dgamma.data_ptr(), dbeta.data_ptr(), ops.dt(z), n,
@@ -82,9 +82,9 @@ def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=F
     return dz, g_out, dgamma, dbeta
 
 
-def channel_sum(z):
+def channel_sum(z, out=None):
     c = z.shape[-1]
-    out = torch.empty(c, device=z.device)
+    out = torch.empty(c, device=z.device) if out is None else out
     ws = _ws(query("erf_bn_workspace_bytes", c), z.device)
     call("erf_channel_sum", z.data_ptr(), ops.dt(z), z.numel() // c, c, out.data_ptr(), ws.data_ptr(), _stream())
     return out
@@ -98,9 +98,9 @@ def conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation):
     return dx
 
 
-def conv1d_wgrad(x, dz, wshape, axis, dilation):
+def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None):
     n, h, w, c = x.shape
-    dw = torch.empty(wshape, device=x.device)
+    dw = torch.empty(wshape, device=x.device) if out is None else out
     nb = query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
     ws = _ws(nb, x.device)
     call("erf_conv1d_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ops.dt(x), n, h, w, c, axis, dilation,
@@ -116,6 +116,30 @@ def dropout_mask(n, c, p, dev, forced=None):
     mask = torch.empty(n * c, device=dev)
     call("erf_dropout2d_mask", mask.data_ptr(), n * c, float(p), seed, _stream())
     return mask.view(n, c)
+
+
+class _Sink:
+    """Where a block's parameter gradients go.  Default: fresh tensors returned to autograd (plain
+    torch optimisers work).  When a trainer attached `_erf_grad_sink` (parameter name -> view of its
+    flat fp32 gradient arena) to the module, the kernels write straight into the arena, autograd gets
+    None for those parameters, and `_erf_after_backward` (if set) is called once the block's gradients
+    are enqueued -- the hook gradient-bucket all-reduces hang on."""
+
+    def __init__(self, mod):
+        self.views = mod.__dict__.get("_erf_grad_sink") if mod is not None else None
+        self.after = mod.__dict__.get("_erf_after_backward") if mod is not None else None
+
+    def out(self, name, shape, dev):
+        if self.views is not None:
+            return self.views[name]
+        return torch.empty(shape, device=dev)
+
+    def ret(self, *grads):
+        if self.views is not None:
+            if self.after is not None:
+                self.after()
+            return tuple(None for _ in grads)
+        return grads
 
 
 def _grad_nhwc(g, like):
@@ -143,7 +167,7 @@ class _NB1dFn(torch.autograd.Function):
             mask = dropout_mask(xh.shape[0], xh.shape[3], mod.dropout.p, xh.device, mod.__dict__.get("_erf_forced_mask"))
         out = bn_apply(z4, mean2, s2, t2, residual=xh, mask=mask)
         ctx.save_for_backward(xh, a1, z2, a2, a3, z4, out, mean1, invstd1, mean2, invstd2, w1, w2, w3, w4, g1, g2)
-        ctx.mask, ctx.d, ctx.training = mask, d, training
+        ctx.mask, ctx.d, ctx.training, ctx.mod = mask, d, training, mod
         return ops.to_nchw_view(out)
 
     @staticmethod
@@ -151,21 +175,25 @@ class _NB1dFn(torch.autograd.Function):
         xh, a1, z2, a2, a3, z4, out, mean1, invstd1, mean2, invstd2, w1, w2, w3, w4, g1, g2 = ctx.saved_tensors
         code, d = ops.dt(xh), ctx.d
         g = _grad_nhwc(gout, xh)
-        dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True)
-        db4 = channel_sum(dz4)
-        dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d)
+        sk, dev, c = _Sink(ctx.mod), xh.device, xh.shape[3]
+        o = lambda name, shape: sk.out(name, shape, dev)
+        dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True,
+                                            dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
+        db4 = channel_sum(dz4, o("conv1x3_2.bias", (c,)))
+        dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
         dz3 = conv1d_dgrad(dz4, ops.pack_conv1d(w4, code, 1), a3, None, AXIS_W, d)
-        db3 = channel_sum(dz3)
-        dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d)
+        db3 = channel_sum(dz3, o("conv3x1_2.bias", (c,)))
+        dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape))
         da2 = conv1d_dgrad(dz3, ops.pack_conv1d(w3, code, 1), None, None, AXIS_H, d)
-        dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training)
-        db2 = channel_sum(dz2)
-        dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1)
+        dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
+                                        dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
+        db2 = channel_sum(dz2, o("conv1x3_1.bias", (c,)))
+        dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
         dz1 = conv1d_dgrad(dz2, ops.pack_conv1d(w2, code, 1), a1, None, AXIS_W, 1)
-        db1 = channel_sum(dz1)
-        dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1)
+        db1 = channel_sum(dz1, o("conv3x1_1.bias", (c,)))
+        dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape))
         dx = conv1d_dgrad(dz1, ops.pack_conv1d(w1, code, 1), None, g_res, AXIS_H, 1)
-        return (ops.to_nchw_view(dx), None, dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)
+        return (ops.to_nchw_view(dx), None) + sk.ret(dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)
 
 
 # --------------------------------------------------------------------------- DownsamplerBlock
@@ -187,7 +215,7 @@ class _DownFn(torch.autograd.Function):
         mean, invstd, s, t = bn_forward_stats(z, mod.bn, mod.training)
         out = bn_apply(z, mean, s, t)
         ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
-        ctx.cin, ctx.cout, ctx.training, ctx.code = cin, cout, mod.training, code
+        ctx.cin, ctx.cout, ctx.training, ctx.code, ctx.mod = cin, cout, mod.training, code, mod
         ctx.need_dx = x.requires_grad
         return ops.to_nchw_view(out)
 
@@ -198,9 +226,12 @@ class _DownFn(torch.autograd.Function):
         cc = cout - cin
         dev = z.device
         g = _grad_nhwc(gout, z)
-        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training)
-        db = channel_sum(dz)[:cc].contiguous()
-        dw = torch.empty(w.shape, device=dev)
+        sk = _Sink(ctx.mod)
+        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
+                                           dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
+        db = sk.out("conv.bias", (cc,), dev)
+        db.copy_(channel_sum(dz)[:cc])
+        dw = sk.out("conv.weight", w.shape, dev)
         n, ho, wo, _ = z.shape
         if cin == 3:
             cpad = 8 if code == BF16 else 4
@@ -210,7 +241,7 @@ class _DownFn(torch.autograd.Function):
             ws = _ws(nb, dev)
             call("erf_stem_wgrad", xpad.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, ws.data_ptr(), nb,
                  _stream())
-            return None, None, dw, db, dgamma, dbeta
+            return (None, None) + sk.ret(dw, db, dgamma, dbeta)
         nb = query("erf_wgrad_workspace_bytes", cc, cin, 9, n * ho * wo)
         ws = _ws(nb, dev)
         call("erf_downsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
@@ -225,7 +256,7 @@ class _DownFn(torch.autograd.Function):
             call("erf_maxpool2x2_backward", xh.data_ptr(), dz.data_ptr(), dxh.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
                  cc, 1, _stream())
             dx = ops.to_nchw_view(dxh)
-        return dx, None, dw, db, dgamma, dbeta
+        return (dx, None) + sk.ret(dw, db, dgamma, dbeta)
 
 
 # --------------------------------------------------------------------------- UpsamplerBlock
@@ -238,7 +269,7 @@ class _UpFn(torch.autograd.Function):
         mean, invstd, s, t = bn_forward_stats(z, mod.bn, mod.training)
         out = bn_apply(z, mean, s, t)
         ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
-        ctx.training = mod.training
+        ctx.training, ctx.mod = mod.training, mod
         return ops.to_nchw_view(out)
 
     @staticmethod
@@ -248,9 +279,11 @@ class _UpFn(torch.autograd.Function):
         n, h, wd, cin = xh.shape
         cout = z.shape[3]
         g = _grad_nhwc(gout, z)
-        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training)
-        db = channel_sum(dz)
-        dw = torch.empty(w.shape, device=dev)
+        sk = _Sink(ctx.mod)
+        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
+                                           dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
+        db = channel_sum(dz, sk.out("conv.bias", (cout,), dev))
+        dw = sk.out("conv.weight", w.shape, dev)
         nb = query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)
         ws = _ws(nb, dev)
         call("erf_upsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, cout, ws.data_ptr(), nb,
@@ -259,18 +292,19 @@ class _UpFn(torch.autograd.Function):
         call("erf_upsampler_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, cin, cout, _stream())
         dxh = torch.empty_like(xh)
         call("erf_upsampler_dgrad", dz.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, cin, cout, _stream())
-        return ops.to_nchw_view(dxh), None, dw, db, dgamma, dbeta
+        return (ops.to_nchw_view(dxh), None) + sk.ret(dw, db, dgamma, dbeta)
 
 
 # --------------------------------------------------------------------------- Decoder.output_conv
 class _OutConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, logits_f32):
+    def forward(ctx, x, w, b, logits_f32, mod=None):
         xh = ops.to_nhwc(x)
         code = ops.dt(xh)
         nc = w.shape[1]
         logits, _ = ops.output_conv(xh, ops.pack_output_conv(w, code), _f32(b), nc, True, logits_f32, False)
         ctx.save_for_backward(xh, w)
+        ctx.mod = mod
         return logits
 
     @staticmethod
@@ -283,8 +317,10 @@ class _OutConvFn(torch.autograd.Function):
         ld = query("erf_output_conv_patch_channels", nc)
         patches = torch.empty((n, h, wd, ld), dtype=xh.dtype, device=dev)
         call("erf_output_conv_patches", glogits.data_ptr(), ops.dt(glogits), patches.data_ptr(), code, n, h, wd, nc, _stream())
-        db = channel_sum(patches)[: 4 * nc].reshape(nc, 4).sum(1)
-        dw = torch.empty(w.shape, device=dev)
+        sk = _Sink(ctx.mod)
+        db = sk.out("bias", (nc,), dev)
+        db.copy_(channel_sum(patches)[: 4 * nc].reshape(nc, 4).sum(1))
+        dw = sk.out("weight", w.shape, dev)
         nb = query("erf_wgrad_workspace_bytes", 4 * nc, 16, 1, n * h * wd)
         ws = _ws(nb, dev)
         call("erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc, ws.data_ptr(), nb,
@@ -293,7 +329,7 @@ class _OutConvFn(torch.autograd.Function):
         call("erf_output_conv_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, nc, _stream())
         dxh = torch.empty_like(xh)
         call("erf_output_conv_dgrad", patches.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, nc, _stream())
-        return ops.to_nchw_view(dxh), dw, db, None
+        return (ops.to_nchw_view(dxh),) + sk.ret(dw, db) + (None, None)
 
 
 # --------------------------------------------------------------------------- dispatch from the modules
@@ -329,7 +365,7 @@ def decoder_forward(dec, x, logits_f32=True):
     y = x
     for layer in dec.layers:
         y = block_forward(layer, y)
-    return _OutConvFn.apply(y, dec.output_conv.weight, dec.output_conv.bias, logits_f32)
+    return _OutConvFn.apply(y, dec.output_conv.weight, dec.output_conv.bias, logits_f32, dec.output_conv)
 
 
 def erfnet_forward(net, x):

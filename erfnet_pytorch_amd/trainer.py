@@ -1,0 +1,195 @@
+"""Training step of /root/reference/train/main.py:162-208 on one process per GPU.
+
+The reference wraps the model in nn.DataParallel (train/main.py:543): one process, batch split
+over the GPUs, per-replica BatchNorm statistics, the loss taken over the gathered global batch
+on GPU 0, gradients summed there, Adam on GPU 0, parameters re-broadcast every step.  Here every
+rank owns a full replica and a shard of the batch:
+
+  * parameters live in ONE flat fp32 arena (registration order), gradients in a second arena the
+    backward kernels write into directly (autograd._Sink), Adam moments in two more;
+  * the loss is  sum_ranks(num) / sum_ranks(den)  (loss.weighted_cross_entropy with the process
+    group), so the summed gradients equal the reference's global-batch gradient;
+  * the gradient arena is all-reduced (RCCL, sum) in three buckets that complete in backward order
+    -- decoder, 128-channel encoder stage, the rest -- each launched as soon as its last block's
+    backward is enqueued, overlapping the remaining backward; BatchNorm stays per-GPU;
+  * one fused Adam launch per active parameter range; parameters that took no part in the forward
+    (`encoder.output_conv` in the full network) are left untouched, like torch.optim.Adam skipping
+    `grad is None` (no weight decay on them either);
+  * replicas stay bit-identical because every rank applies the same reduced gradient.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import torch
+
+from . import erfnet as E
+from ._lib import call
+from .loss import weighted_cross_entropy
+
+# train/main.py:92-111 (20-class Cityscapes recipe; class 19 = ignore)
+CITYSCAPES_WEIGHTS = [
+    2.8149201869965, 6.9850029945374, 3.7890393733978, 9.9428062438965, 9.7702074050903,
+    9.5110931396484, 10.311357498169, 10.026463508606, 4.6323022842407, 9.5608062744141,
+    7.8698215484619, 9.5168733596802, 10.373730659485, 6.6616044044495, 10.260489463806,
+    10.287888526917, 10.289801597595, 10.405355453491, 10.138095855713, 0.0,
+]
+
+
+def poly_lr(base_lr, epoch, num_epochs):
+    """lr schedule of train/main.py:156-157 (epoch is 1-based, stepped at :165)."""
+    return base_lr * math.pow(1 - ((epoch - 1) / num_epochs), 0.9)
+
+
+class Trainer:
+    def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
+                 group=None, world_size=1, overlap=True):
+        self.model = model
+        self.group, self.world = group, world_size
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.overlap = overlap and world_size > 1
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.weight = None if class_weights is None else torch.tensor(class_weights, dtype=torch.float32, device=dev)
+
+        named = list(model.named_parameters())
+        total = sum(p.numel() for _, p in named)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = {}
+        off = 0
+        for name, p in named:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + n].view_as(p)
+            self.offsets[name] = (off, n)
+            off += n
+
+        # gradient sinks: every block's kernels write into views of gflat
+        for mname, mod in model.named_modules():
+            own = {k: v for k, v in mod.named_parameters(recurse=True)} if isinstance(
+                mod, (E.DownsamplerBlock, E.UpsamplerBlock, E.non_bottleneck_1d)) else None
+            if own is None and mod is model.decoder.output_conv:
+                own = dict(mod.named_parameters())
+            if own is None:
+                continue
+            views = {}
+            for k, prm in own.items():
+                o, n = self.offsets[f"{mname}.{k}"]
+                views[k] = self.gflat[o:o + n].view_as(prm)
+            mod.__dict__["_erf_grad_sink"] = views
+
+        # active ranges (everything except the encoder-only head) and all-reduce buckets
+        def rng(prefixes):
+            keys = [k for k in self.offsets if any(k.startswith(p) for p in prefixes)]
+            lo = min(self.offsets[k][0] for k in keys)
+            hi = max(self.offsets[k][0] + self.offsets[k][1] for k in keys)
+            return lo, hi
+
+        self.buckets = [
+            rng(["decoder."]),
+            rng([f"encoder.layers.{i}." for i in range(6, 15)]),
+            rng(["encoder.initial_block."] + [f"encoder.layers.{i}." for i in range(0, 6)]),
+        ]
+        head = rng(["encoder.output_conv."])
+        enc = (self.buckets[2][0], self.buckets[1][1])
+        assert enc[1] == head[0] and head[1] == self.buckets[0][0], "arena order changed"
+        self.active = [enc, self.buckets[0]]
+        self._pending = []
+        if self.overlap:
+            model.decoder.layers[0].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(0)
+            model.encoder.layers[6].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(1)
+            model.encoder.initial_block.__dict__["_erf_after_backward"] = lambda: self._launch_bucket(2)
+
+    # -- collectives ------------------------------------------------------------------------
+    def _launch_bucket(self, i):
+        import torch.distributed as dist
+        lo, hi = self.buckets[i]
+        self._pending.append(dist.all_reduce(self.gflat[lo:hi], group=self.group, async_op=True))
+
+    def _reduce_gradients(self):
+        if self.world == 1:
+            return
+        if not self.overlap:
+            for i in range(len(self.buckets)):
+                self._launch_bucket(i)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    # -- one optimisation step ----------------------------------------------------------------
+    def set_epoch(self, epoch, num_epochs, base_lr=5e-4):
+        self.lr = poly_lr(base_lr, epoch, num_epochs)
+
+    def zero_grad(self):
+        self.gflat.zero_()
+
+    def step(self, images, targets):
+        """images [N,3,H,W]; targets [N,1,H,W] or [N,H,W] int64.  Returns the (global) loss tensor."""
+        if targets.dim() == 4:
+            targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
+        outputs = self.model(images)
+        loss = weighted_cross_entropy(outputs, targets, self.weight, self.group if self.world > 1 else None)
+        loss.backward()
+        self._reduce_gradients()
+        self.optimizer_step()
+        return loss.detach(), outputs.detach()
+
+    def optimizer_step(self):
+        self.step_count += 1
+        st = torch.cuda.current_stream().cuda_stream
+        for lo, hi in self.active:
+            call("erf_adam_fused_arena", self.flat[lo:hi].data_ptr(), self.gflat[lo:hi].data_ptr(),
+                 self.exp_avg[lo:hi].data_ptr(), self.exp_avg_sq[lo:hi].data_ptr(), hi - lo, float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_count, 1.0, st)
+
+
+# ------------------------------------------------------------------------------------------ benchmark leg
+def bench_train(args, world, rank, dev, barrier, max_over_ranks):
+    """BASELINE.json configs[2]: ERFNet(20) training, batch 6 per GPU, 3x512x1024 synthetic images,
+    weighted cross-entropy (20-class weights, w[19] = 0), Adam, dropout on, data parallel over `world` ranks."""
+    import torch.distributed as dist
+    from . import synthetic as S
+    batch = args.batch or 6
+    model = E.ERFNet(20)
+    S.load_synthetic(model)
+    model = model.to(dev).train()
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    group = dist.group.WORLD if world > 1 else None
+    tr = Trainer(model, CITYSCAPES_WEIGHTS, group=group, world_size=world)
+    torch.manual_seed(1234 + rank)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(batch, 3, args.height, args.width, device=dev, generator=gen)
+    t = torch.randint(0, 20, (batch, 1, args.height, args.width), device=dev, generator=gen)
+    t[torch.rand(t.shape, device=dev, generator=gen) < 0.05] = 19
+
+    def step():
+        tr.zero_grad()
+        return tr.step(x, t)
+
+    for _ in range(max(args.warmup, 1)):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    flop_img = 2 * (3 * 26_612_727_808 - 46_006_272) * (args.height * args.width) / (512 * 1024)
+    value = world * batch * args.steps / elapsed
+    return {
+        "metric": "img/s ERFNet 512x1024: bf16 inference (1 GPU) + training (1/2/4/8 MI355X)",
+        "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"ERFNet(20) training step (fwd + weighted CE + bwd + RCCL grad all-reduce + Adam), batch {batch}/GPU, "
+                               f"3x{args.height}x{args.width}, data parallel x{world}",
+                   "global_batch": batch * world, "final_loss": float(loss)},
+        "model_tflops": value * flop_img / 1e12,
+    }

@@ -326,3 +326,60 @@ def test_dropout_mask_statistics():
         assert abs(frac - p) < 5 * sigma, (frac, p)
         m2 = ag.dropout_mask(64, 128, p, torch.device(DEV)).cpu()
         assert not torch.equal(m, m2)                     # a fresh mask per call
+
+
+def test_trainer_step_matches_golden_and_autograd():
+    """Trainer (flat arenas, gradient sinks, fused Adam) == plain autograd grads + the reference's first Adam step."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.loss import CrossEntropyLoss2d
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS, poly_lr
+    assert CITYSCAPES_WEIGHTS == O.CITYSCAPES_WEIGHTS
+    g = load("g5_train_steps.npz")
+    sd = O.synthetic_state(O.erfnet_template(20))
+    x = S.synthetic_images(2, 64, 128, seed=50).to(DEV)
+    t = S.synthetic_labels(2, 64, 128, 20, seed=50).to(DEV)
+
+    def build():
+        m = E.ERFNet(20)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        for name, mod in m.named_modules():
+            if f"s0_mask_{name}" in g.files:
+                mod.__dict__["_erf_forced_mask"] = torch.from_numpy(g[f"s0_mask_{name}"])
+        return m
+
+    ref_model = build()
+    loss_ref = CrossEntropyLoss2d(torch.tensor(O.CITYSCAPES_WEIGHTS)).to(DEV)(ref_model(x), t[:, 0])
+    loss_ref.backward()
+    model = build()
+    tr = Trainer(model, CITYSCAPES_WEIGHTS)
+    tr.lr = poly_lr(5e-4, 1, 150)
+    assert abs(tr.lr - float(g["s0_lr"])) < 1e-12
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    tr.zero_grad()
+    loss, _ = tr.step(x, t)
+    assert loss.item() == loss_ref.item()
+    # the arena holds exactly the gradients plain autograd produced (same kernels, same order)
+    for k, p in ref_model.named_parameters():
+        o, n = tr.offsets[k]
+        if p.grad is None:
+            assert k.startswith("encoder.output_conv") and float(tr.gflat[o:o + n].abs().sum()) == 0.0
+            assert torch.equal(dict(model.named_parameters())[k].detach(), before[k])     # untouched: no weight decay either
+        else:
+            assert torch.equal(tr.gflat[o:o + n].view_as(p), p.grad), k
+    # parameters after the step vs the reference's torch.optim.Adam (sum over each tensor)
+    names = [str(s) for s in g["param_names"]]
+    params = dict(model.named_parameters())
+    ps = np.array([params[k].detach().double().sum().item() for k in names])
+    pa = g["s0_paramabs"]
+    keep = np.array([not pre_bn_bias(k) for k in names])
+    # |update| <= lr per element; a flipped gradient sign (noise-level gradients) moves an element by 2*lr
+    n_el = np.array([params[k].numel() for k in names])
+    flips = np.maximum(np.ceil(0.02 * n_el), 2)
+    assert np.all((np.abs(ps - g["s0_paramsum"]) <= 1e-5 * np.maximum(pa, 1e-3) + flips * 2 * tr.lr)[keep])
+    # Adam update itself, element-wise, against the oracle's Adam on OUR gradients
+    for k in ("decoder.output_conv.weight", "encoder.layers.7.conv3x1_1.weight", "encoder.initial_block.bn.weight"):
+        p0, gk = before[k].cpu(), ref_model.get_parameter(k).grad.cpu()
+        m0, v0 = torch.zeros_like(p0), torch.zeros_like(p0)
+        O.adam_step([p0], [gk], [m0], [v0], 1, lr=tr.lr)
+        assert rel_err(params[k].detach().cpu(), p0) <= 1e-6, k
