@@ -73,20 +73,41 @@ static int red_groups(long long P, int C) {
 size_t bn_workspace_bytes(int C) { return (size_t)RED_MAX_GROUPS * 2 * C * sizeof(double) + 4 * C * sizeof(float); }
 float* bn_workspace_coef(void* workspace, int C) { return (float*)((double*)workspace + (size_t)RED_MAX_GROUPS * 2 * C); }
 
+
+// Sum the fp64 partials [groups][2C] per channel with all 1024 threads of the block: thread
+// (part, c) adds groups part, part + nparts, ...; the parts meet in LDS.  On return threads
+// tid < C hold the two column sums of channel tid.
+#define FIN_THREADS 1024
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int groups, int C, double& s, double& ss) {
+    __shared__ double sh[2 * FIN_THREADS];
+    const int nparts = FIN_THREADS / C;
+    const int c = threadIdx.x % C, part = threadIdx.x / C;
+    double a = 0, b = 0;
+    if (part < nparts)
+        for (int g = part; g < groups; g += nparts) {
+            a += partials[(long long)g * 2 * C + c];
+            b += partials[(long long)g * 2 * C + C + c];
+        }
+    sh[threadIdx.x] = a;
+    sh[FIN_THREADS + threadIdx.x] = b;
+    __syncthreads();
+    s = 0; ss = 0;
+    if (threadIdx.x < C)
+        for (int k = 0; k < nparts; ++k) { s += sh[k * C + threadIdx.x]; ss += sh[FIN_THREADS + k * C + threadIdx.x]; }
+}
+
 __global__ void channel_sum_finalize_kernel(const double* __restrict__ partials, int groups, int C, float* __restrict__ sums) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0;
-        for (int g = 0; g < groups; ++g) s += partials[(long long)g * 2 * C + c];
-        sums[c] = (float)s;
-    }
+    double s, ss;
+    reduce_partials(partials, groups, C, s, ss);
+    if (threadIdx.x < C) sums[threadIdx.x] = (float)s;
 }
 
 int channel_sum_finalize_launch(const float* partials, int groups, int C, float* sums, hipStream_t stream) {
-    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(1), dim3(128), 0, stream, (const double*)partials, groups, C, sums);
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, sums);
     return erf_check_launch();
 }
 
-static bool chan_ok(int C) { return C > 0 && (C & 3) == 0 && C <= 1024; }
+static bool chan_ok(int C) { return C > 0 && (C & 3) == 0 && C <= 512; }
 
 int bn_stats_launch(const void* z, int dtype, long long P, int C, float* partials, int* groups, hipStream_t stream) {
     if (!chan_ok(C)) return ERF_EUNSUPPORTED;
@@ -109,9 +130,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partials, int grou
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                    float eps, float* __restrict__ mean, float* __restrict__ invstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0, ss = 0;
-        for (int g = 0; g < groups; ++g) { s += partials[(long long)g * 2 * C + c]; ss += partials[(long long)g * 2 * C + C + c]; }
+    double s, ss;
+    reduce_partials(partials, groups, C, s, ss);
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
         const double m = s / count;
         double var = ss / count - m * m;
         if (var < 0) var = 0;
@@ -132,7 +154,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partials, int grou
 int bn_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                        float* scale, float* shift, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, stream, (const double*)partials, groups, C, (double)count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, (double)count, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return erf_check_launch();
 }
@@ -212,9 +234,10 @@ int bn_bwd_reduce_launch(const void* g, const void* gate, const float* mask, con
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int groups, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd, int batch_stats,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0, sx = 0;
-        for (int g = 0; g < groups; ++g) { s += partials[(long long)g * 2 * C + c]; sx += partials[(long long)g * 2 * C + C + c]; }
+    double s, sx;
+    reduce_partials(partials, groups, C, s, sx);
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
         dbeta[c] = (float)s;
         dgamma[c] = (float)sx;
         coef[c] = gamma[c] * invstd[c];
@@ -225,7 +248,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int 
 
 int bn_bwd_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma,
                            const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* coef, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, stream, (const double*)partials, groups, C, (double)count, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, (double)count, gamma,
                        invstd, batch_stats, dgamma, dbeta, coef);
     return erf_check_launch();
 }
@@ -518,28 +541,40 @@ int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, dou
 template <typename TS, typename T>
 __global__ __launch_bounds__(256) void patches_kernel(const TS* __restrict__ dl, T* __restrict__ out, int N, int H, int W,
                                                       int nc, int ncp, int ld) {
-    const long long total = (long long)N * H * W * 4 * ncp;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        // iterate with the pixel fastest so that plane reads coalesce
-        const long long P = (long long)N * H * W;
-        const long long pix = idx % P;
-        const int v = (int)(idx / P);
-        const int cls = v >> 2, ph = v & 3;
-        const int j = (int)(pix % W);
-        const long long rest = pix / W;
-        const int i = (int)(rest % H);
-        const int n = (int)(rest / H);
+    // one block = 64 consecutive input pixels of one image row-major range; tile[px][v] in LDS
+    extern __shared__ float tile[];                 // [64][ld + 1]
+    const long long P = (long long)N * H * W;
+    const long long pix0 = (long long)blockIdx.x * 64;
+    const int ldt = ld + 1;
+    // read: lanes run over the 64 pixels (stride-2 floats inside a plane row), v over the warps
+    for (int id = threadIdx.x; id < 64 * ld; id += 256) {
+        const int px = id & 63, v = id >> 6;
+        const long long pix = pix0 + px;
         float val = 0.f;
-        if (cls < nc)
+        const int cls = v >> 2, ph = v & 3;
+        if (pix < P && cls < nc) {
+            const int j = (int)(pix % W);
+            const long long rest = pix / W;
+            const int i = (int)(rest % H);
+            const int n = (int)(rest / H);
             val = Elem<TS>::ld(dl + (((long long)n * nc + cls) * (2 * H) + 2 * i + (ph >> 1)) * (2 * W) + 2 * j + (ph & 1));
-        Elem<T>::st(out + pix * ld + v, val);
+        }
+        tile[px * ldt + v] = val;
+    }
+    __syncthreads();
+    // write: the 64 pixels x ld channels are one contiguous run of the NHWC tensor
+    for (int id = threadIdx.x; id < 64 * ld; id += 256) {
+        const int px = id / ld, v = id % ld;
+        if (pix0 + px < P) Elem<T>::st(out + (pix0 + px) * ld + v, tile[px * ldt + v]);
     }
 }
 
 int patches_launch(const void* dl, int src_dtype, void* out, int dtype, int N, int H, int W, int nc, int ncp, int ld,
                    hipStream_t stream) {
-    const long long total = (long long)N * H * W * 4 * ncp;
-#define PK(TS, T) hipLaunchKernelGGL((patches_kernel<TS, T>), dim3(ew_grid(total)), dim3(256), 0, stream, (const TS*)dl, (T*)out, N, H, W, nc, ncp, ld)
+    const long long blocks = ((long long)N * H * W + 63) / 64;
+    if (blocks > 0x7FFFFFFFLL) return ERF_EINVAL;
+    const size_t lds = (size_t)64 * (ld + 1) * sizeof(float);
+#define PK(TS, T) hipLaunchKernelGGL((patches_kernel<TS, T>), dim3((unsigned)blocks), dim3(256), lds, stream, (const TS*)dl, (T*)out, N, H, W, nc, ncp, ld)
     if (src_dtype == 0 && dtype == 0) PK(float, float);
     else if (src_dtype == 0 && dtype == 1) PK(float, bf16raw);
     else if (src_dtype == 1 && dtype == 1) PK(bf16raw, bf16raw);

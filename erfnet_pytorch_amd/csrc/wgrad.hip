@@ -169,17 +169,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int tap = col / cin, ci = col % cin;
     const int phase = row / m.ncp, cls = row % m.ncp;
     if (cls >= m.nc_valid || (m.cin_valid && ci >= m.cin_valid)) return;
-    double s = 0;
     const long long stride = (long long)rows_pad * ncols_pad;
     const float* src = partial + (long long)row * ncols_pad + col;
-    for (int g = 0; g < nwg; ++g) s += src[g * stride];
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};                  // four independent chains keep the loads in flight
+    int g = 0;
+    for (; g + 4 <= nwg; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += src[(g + u) * stride];
+    }
+    for (; g < nwg; ++g) s4[0] += src[g * stride];
+    const double s = ((double)s4[0] + (double)s4[1]) + ((double)s4[2] + (double)s4[3]);
     dw[(long long)cls * m.s_co + (long long)phase * m.s_phase + (long long)ci * m.s_ci + m.toff[tap]] = (float)s;
 }
 
 static void plan(long long P, int* nwg, int* spw) {
     const long long steps = (P + 31) / 32;
-    long long s = (steps + 255) / 256;
-    if (s < 8) s = 8;
+    long long s = (steps + 127) / 128;
+    if (s < 16) s = 16;
     *spw = (int)s;
     *nwg = (int)((steps + s - 1) / s);
 }
