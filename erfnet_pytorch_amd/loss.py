@@ -17,6 +17,7 @@ import torch
 
 from . import ops
 from ._lib import call, query
+from .dp import global_weighted_mean
 
 
 def _stream():
@@ -40,13 +41,7 @@ class _WeightedCE(torch.autograd.Function):
         ws = torch.empty(query("erf_ce_workspace_bytes"), dtype=torch.uint8, device=dev)
         call("erf_weighted_ce_fwd", logits.data_ptr(), ops.dt(logits), target.data_ptr(), 0 if wt is None else wt.data_ptr(),
              n, c, h * w, out3.data_ptr(), ws.data_ptr(), _stream())
-        if group is not None:
-            import torch.distributed as dist
-            parts = out3[:2].clone()
-            dist.all_reduce(parts, group=group)
-            num, den = parts[0], parts[1]
-        else:
-            num, den = out3[0], out3[1]
+        num, den = global_weighted_mean(out3[0], out3[1], group)
         ctx.save_for_backward(logits, target, den.reshape(1))
         ctx.weight = wt
         return num / den

@@ -24,6 +24,7 @@ import time
 
 import torch
 
+from . import dp
 from . import erfnet as E
 from ._lib import call
 from .loss import weighted_cross_entropy
@@ -83,22 +84,8 @@ class Trainer:
                 views[k] = self.gflat[o:o + n].view_as(prm)
             mod.__dict__["_erf_grad_sink"] = views
 
-        # active ranges (everything except the encoder-only head) and all-reduce buckets
-        def rng(prefixes):
-            keys = [k for k in self.offsets if any(k.startswith(p) for p in prefixes)]
-            lo = min(self.offsets[k][0] for k in keys)
-            hi = max(self.offsets[k][0] + self.offsets[k][1] for k in keys)
-            return lo, hi
-
-        self.buckets = [
-            rng(["decoder."]),
-            rng([f"encoder.layers.{i}." for i in range(6, 15)]),
-            rng(["encoder.initial_block."] + [f"encoder.layers.{i}." for i in range(0, 6)]),
-        ]
-        head = rng(["encoder.output_conv."])
-        enc = (self.buckets[2][0], self.buckets[1][1])
-        assert enc[1] == head[0] and head[1] == self.buckets[0][0], "arena order changed"
-        self.active = [enc, self.buckets[0]]
+        # all-reduce buckets (backward-completion order) and the ranges Adam may touch
+        self.buckets, self.active = dp.bucket_ranges(self.offsets)
         self._pending = []
         if self.overlap:
             model.decoder.layers[0].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(0)

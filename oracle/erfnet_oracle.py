@@ -157,7 +157,7 @@ def erfnet_imagenet(sd: SD, x: torch.Tensor, st: Optional[RunState] = None) -> t
 def weighted_ce_parts(logits: torch.Tensor, target: torch.Tensor, weight: Optional[torch.Tensor]):
     """(sum_p w[t_p] * nll_p, sum_p w[t_p]) -- the numerator and denominator of
     torch.nn.CrossEntropyLoss(weight) with reduction='mean' (train/main.py:121)."""
-    logp = F.log_softmax(logits.float(), dim=1)
+    logp = F.log_softmax(logits if logits.dtype == torch.float64 else logits.float(), dim=1)
     nll = -logp.gather(1, target[:, None]).squeeze(1)
     w = weight[target] if weight is not None else torch.ones_like(nll)
     return (w * nll).sum(), w.sum()
