@@ -53,6 +53,15 @@ int erf_conv1d_factorized(const void* x, void* y, const void* packed, const floa
     return gconv_launch(p, dtype, C, (hipStream_t)stream);
 }
 
+int erf_conv1d_pair(const void* x, void* y, const void* packed_a, const void* packed_b, const float* scale_a, const float* shift_a,
+                    const float* scale_b, const float* shift_b, const void* residual, int dtype, int N, int H, int W, int C,
+                    int dilation, int relu, void* stream) {
+    if (!x || !y || !packed_a || !packed_b || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || dilation < 1) return ERF_EINVAL;
+    if (x == y) return ERF_EINVAL;
+    return conv1d_pair_launch(x, y, packed_a, packed_b, scale_a, shift_a, scale_b, shift_b, residual, dtype, N, H, W, C, dilation,
+                              relu, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ DownsamplerBlock
 size_t erf_downsampler_packed_bytes(int dtype, int Cin, int Cout) {
     if (!dtype_ok(dtype) || Cin <= 0 || Cout <= Cin) return 0;

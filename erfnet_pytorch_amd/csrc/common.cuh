@@ -39,6 +39,19 @@ __device__ __forceinline__ bf16raw f32_to_bf16(float f) {
     return __builtin_bit_cast(bf16raw, h);
 }
 
+// Two / four fp32 -> packed bf16 (RNE), one v_cvt_pk_bf16_f32 per pair.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ int pack_bf16x2(float lo, float hi) {
+    const f32x2 v{lo, hi};
+    return __builtin_bit_cast(int, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ i32x2 pack_bf16x4(const f32x4& v) {
+    i32x2 r;
+    r[0] = pack_bf16x2(v[0], v[1]);
+    r[1] = pack_bf16x2(v[2], v[3]);
+    return r;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int EPC = 4;               // elements per 16-byte chunk
@@ -89,10 +102,7 @@ template <> __device__ __forceinline__ f32x4 load4<bf16raw>(const bf16raw* p) {
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
 template <> __device__ __forceinline__ void store4<bf16raw>(bf16raw* p, f32x4 v) {
-    i32x2 r;
-    r[0] = (int)((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16));
-    r[1] = (int)((uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
-    *(i32x2*)p = r;
+    *(i32x2*)p = pack_bf16x4(v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -22,17 +22,8 @@
 //  * 2 workgroups per CU (single LDS buffer each): one stages while the other computes.
 #include "common.cuh"
 #include "conv1d.cuh"
+#include "conv1d_tile.cuh"
 #include <stdlib.h>
-#include <type_traits>
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 struct Conv1dParams {
     const void* x;
     void* y;
@@ -227,19 +218,6 @@ void conv1d_kernel(const Conv1dParams p) {
 //    read with the same coalesced pattern.  With a residual or gate in bf16 the value is rounded
 //    to bf16 once before and once after that operand is applied.
 // =====================================================================================
-static __device__ __attribute__((aligned(1024))) char g_zero_page[1024];     // never written
-
-template <int PIXB>
-__device__ __forceinline__ int swz(int pix, int chunk) {       // an involution: swz(pix, swz(pix, c)) == c
-    constexpr int CH = PIXB / 16;
-    if constexpr (CH >= 16) {
-        return ((chunk & 15) ^ (pix & 15)) | (chunk & ~15);
-    } else {
-        constexpr int PPR = 16 / CH;
-        return chunk ^ ((pix / PPR) & (CH - 1));
-    }
-}
-
 struct TileGeo {
     long long gp0;
     int a_first, ulo, uhi, vhi;
@@ -263,18 +241,6 @@ __device__ __forceinline__ TileGeo tile_geo(const Conv1dParams& p, int tile) {
     return g;
 }
 
-template <int IMM>
-__device__ __forceinline__ i32x4 lds_read_b128(int addr) {
-    i32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(IMM) : "memory");
-    return r;
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void tie_reg(i32x4& v) { asm volatile("" : "+v"(v)); }
-
-#define ERF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
 template <typename T, int C, int NW, int KI>
 __device__ __forceinline__ void dma_tile(const Conv1dParams& p, const TileGeo& g, const T* xg, char* buf, int wave, int lane) {
     constexpr int EPC = Elem<T>::EPC;
@@ -294,36 +260,6 @@ __device__ __forceinline__ void dma_tile(const Conv1dParams& p, const TileGeo& g
                                          (__attribute__((address_space(3))) void*)(buf + (k * NW + wave) * 1024), 16, 0, 0);
     }
 }
-
-template <typename T> struct ChunkOps;
-template <> struct ChunkOps<float> {
-    static constexpr int N = 4;
-    __device__ static __forceinline__ void unpack(const i32x4& r, float* f) {
-        const f32x4 v = __builtin_bit_cast(f32x4, r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] = v[e];
-    }
-    __device__ static __forceinline__ i32x4 pack(const float* f) {
-        f32x4 v{f[0], f[1], f[2], f[3]};
-        return __builtin_bit_cast(i32x4, v);
-    }
-};
-template <> struct ChunkOps<bf16raw> {
-    static constexpr int N = 8;
-    __device__ static __forceinline__ void unpack(const i32x4& r, float* f) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f[2 * e] = __uint_as_float(((uint32_t)r[e]) << 16);
-            f[2 * e + 1] = __uint_as_float(((uint32_t)r[e]) & 0xFFFF0000u);
-        }
-    }
-    __device__ static __forceinline__ i32x4 pack(const float* f) {
-        i32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = (int)((uint32_t)f32_to_bf16(f[2 * e]) | ((uint32_t)f32_to_bf16(f[2 * e + 1]) << 16));
-        return r;
-    }
-};
 
 template <typename T, int C, int WM, int WN, int M, int KI, int OCC>
 __global__ __launch_bounds__(WM * WN * 64, OCC)

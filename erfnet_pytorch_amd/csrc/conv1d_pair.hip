@@ -1,0 +1,479 @@
+// Fused pair of factorized convolutions (bf16, inference):
+//
+//     y = act( sB * conv1x3_d( relu( sA * conv3x1_d(x) + tA ) ) + tB (+ residual) )
+//
+// i.e. one half of a non_bottleneck_1d block in a single launch: the intermediate feature map
+// never leaves the CU.
+//
+// Tile geometry.  Both convolutions have the same dilation d, so the pixels with
+// (h mod d, w mod d) = (rho_h, rho_w) form an independent undilated 2-D problem (a "lattice").
+// A tile is R consecutive lattice rows x TC consecutive lattice columns of one lattice:
+//   * input  (R+2) x TC pixels, DMA-ed into LDS (double buffered, zeros outside the image);
+//   * GEMM 1 (3x1, taps = LDS rows i, i+1, i+2) produces the R x TC intermediate, written to LDS
+//     as bf16 in rows of TC+2 slots whose first and last slot stay zero (the 1x3 zero padding);
+//     intermediate pixels right of the image are forced to zero for the same reason;
+//   * GEMM 2 (1x3, taps = slots j, j+1, j+2) produces R x TC outputs, of which columns 1..TC-2
+//     are complete; column 0 is complete when the tile starts at the image's left edge and column
+//     TC-1 when it is the lattice's last column.  Tiles therefore advance by TC-2 columns;
+//   * epilogue through LDS with coalesced 16-byte stores, as in the single-convolution kernel.
+// Both weight sets stay in registers for the whole launch.
+//
+// Instruction budget.  Per tile a wave issues 2 x PTW x CTW x KS MFMAs (96 for C = 64 / 128); everything
+// else has to stay well below that, so all per-lane addressing is computed once per launch:
+// global accesses are raw-buffer instructions taking (launch-invariant per-lane offset) + (per-tile
+// scalar offset), out-of-image lanes get an offset beyond the buffer (reads return zeros, stores are
+// dropped), and the tile index is decoded with multiply-high "fast division" on the scalar unit.
+#include "common.cuh"
+#include "conv1d.cuh"
+#include "conv1d_tile.cuh"
+#include <stdlib.h>
+
+typedef bf16raw T;
+
+struct PairParams {
+    const T* x;
+    T* y;
+    const void* wA;
+    const void* wB;
+    const float *scaleA, *shiftA, *scaleB, *shiftB;
+    const T* res;
+    int d, relu;
+    int N, H, W;
+    int CA, CB;      // tiles per lattice along rows / columns
+    int ntiles;
+    FastDiv fCB, fCA, fD;
+    uint32_t bytes;  // N*H*W*C*2
+    uint32_t pad;    // the input descriptor starts `pad` bytes before x so that the halo row above the image has an offset >= 0
+    int dbg;         // diagnostic bit mask (ERF_PAIR_DBG): 1 no image reads, 2 no stores, 4 no MFMA phases
+};
+
+// Per-tile scalars (all wave-uniform).
+struct PairGeo {
+    uint32_t in_soff, out_soff;
+    int ulo, uhi;        // valid input rows u
+    int jhi;             // valid input / intermediate columns j < jhi
+    int ihi;             // valid output rows i < ihi
+    int jlo, jho;        // valid output columns jlo <= j < jho
+};
+
+template <int C, int R, int TC>
+__device__ __forceinline__ PairGeo pair_geo(const PairParams& p, int tile) {
+    constexpr int PIXB = C * 2;
+    PairGeo g;
+    uint32_t t = (uint32_t)tile;
+    uint32_t nq = fast_div(t, p.fCB);
+    const int tw = (int)(t - nq * p.fCB.div); t = nq;
+    nq = fast_div(t, p.fCA);
+    const int th = (int)(t - nq * p.fCA.div); t = nq;
+    nq = fast_div(t, p.fD);
+    const int rho_w = (int)(t - nq * p.fD.div); t = nq;
+    nq = fast_div(t, p.fD);
+    const int rho_h = (int)(t - nq * p.fD.div);
+    const int n = (int)nq;
+    const int nh = (int)fast_div((uint32_t)(p.H - rho_h + p.d - 1), p.fD);      // lattice rows / columns of this residue class
+    const int nw = (int)fast_div((uint32_t)(p.W - rho_w + p.d - 1), p.fD);
+    const int hh0 = th * R - 1, c0 = tw * (TC - 2);
+    const int h1 = rho_h + (hh0 + 1) * p.d, w0 = rho_w + c0 * p.d;
+    g.out_soff = (uint32_t)((n * p.H + h1) * p.W + w0) * PIXB;
+    g.in_soff = g.out_soff;                                       // + pad - one lattice row (pad == d*W*PIXB)
+    g.ulo = hh0 < 0 ? 1 : 0;
+    int uhi = nh - hh0;
+    uhi = tile < p.ntiles ? (uhi < R + 2 ? uhi : R + 2) : 0;
+    g.uhi = uhi > g.ulo ? uhi : g.ulo;                            // empty range when the tile lies below the image
+    const int rem = nw - c0;
+    g.jhi = rem < TC ? rem : TC;
+    const int ihi = nh - hh0 - 1;
+    g.ihi = ihi < R ? ihi : R;
+    g.jlo = tw == 0 ? 0 : 1;
+    g.jho = rem <= TC ? rem : TC - 1;
+    return g;
+}
+
+// The buffer-descriptor type only exists in the device pass, so everything that touches it is
+// compiled there alone (the host pass needs just the kernel's signature for the launch stub).
+#if defined(__HIP_DEVICE_COMPILE__)
+// Input tile -> LDS: KI 16-byte slots per lane; masked slots read zeros (offset beyond the buffer).
+template <int KI, int NW>
+__device__ __forceinline__ void pair_dma(__amdgpu_buffer_rsrc_t rs, char* buf, const uint32_t (&in_rel)[KI], const int (&in_uj)[KI],
+                                         const PairGeo& g, int wave) {
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+        const int u = in_uj[k] >> 16, j = in_uj[k] & 0xFFFF;
+        const bool ok = (unsigned)(u - g.ulo) < (unsigned)(g.uhi - g.ulo) && j < g.jhi;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(buf + (k * NW + wave) * 1024), 16,
+                                                 ok ? in_rel[k] : ERF_OOB, g.in_soff, 0, 0);
+    }
+}
+
+#endif
+
+struct ImmIn {
+    template <int PIXB, int TC> static constexpr int of(int pt, int tap) { return (pt * 16 + tap * TC) * PIXB; }
+    template <int NCL> static constexpr int li(int tap, int cl) { return cl; }
+};
+struct ImmMid {
+    template <int PIXB, int TC> static constexpr int of(int pt, int tap) {
+        return ((pt / (TC / 16)) * (TC + 2) + (pt % (TC / 16)) * 16) * PIXB;
+    }
+    template <int NCL> static constexpr int li(int tap, int cl) { return tap * NCL + cl; }
+};
+
+// One GEMM of the pair: acc[pt][c] += W[c][ks] x B(pt, ks); B fragments come from LDS at
+// lb[class] + immediate through hand-placed reads in groups of GS, group g+1 in flight while group g
+// feeds the MFMAs (LDS reads return in order, so "at most GS outstanding" means group g has arrived).
+template <int C, int TC, int PTW, int CTW, typename IMM>
+__device__ __forceinline__ void mfma_phase(const int* lb, const i32x4 (&wreg)[CTW][(3 * (C / 8) + 3) / 4], f32x4 (&acc)[PTW][CTW], int q) {
+    constexpr int CH = C / 8;
+    constexpr int PIXB = C * 2;
+    constexpr int KS = (3 * CH + 3) / 4;
+    constexpr int NCL = CH >= 4 ? (CH < 16 ? CH : 16) / 4 : 1;
+    constexpr int GS = (KS % 6 == 0) ? 6 : (KS % 4 == 0 ? 4 : KS);
+    constexpr int NG = PTW * KS / GS;
+    static_assert((PTW * KS) % GS == 0, "read groups");
+    i32x4 bb[2][GS];
+    auto issue = [&](auto gi, i32x4* dst) {
+        static_for<0, GS>([&](auto e) {
+            constexpr int r = decltype(gi)::value * GS + decltype(e)::value;
+            constexpr int pt = r / KS, ks = r % KS;
+            constexpr int tap = (ks * 4) / CH;
+            // CH < 4: the tap differs per lane and is folded into lb[ks] together with the chunk
+            constexpr int li = CH >= 4 ? IMM::template li<NCL>(tap, ks % NCL) : ks;
+            constexpr int imm = IMM::template of<PIXB, TC>(pt, CH >= 4 ? tap : 0) + (CH > 16 ? (((ks * 4) % CH) & ~15) * 16 : 0);
+            static_assert(imm < 65536, "ds offset field");
+            dst[decltype(e)::value] = lds_read_b128<imm>(lb[li]);
+        });
+    };
+    issue(std::integral_constant<int, 0>{}, bb[0]);
+    static_for<0, NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        i32x4* cb = bb[g & 1];
+        if constexpr (g + 1 < NG) {
+            issue(std::integral_constant<int, g + 1>{}, bb[(g + 1) & 1]);
+            wait_lgkm<GS>();
+        } else {
+            wait_lgkm<0>();
+        }
+        static_for<0, GS>([&](auto e) { tie_reg(cb[decltype(e)::value]); });
+        static_for<0, GS>([&](auto e) {
+            constexpr int r = g * GS + decltype(e)::value;
+            constexpr int pt = r / KS, ks = r % KS;
+            i32x4 b = cb[decltype(e)::value];
+            if constexpr ((3 * CH) % 4 != 0) {
+                if (ks * 4 + q >= 3 * CH) b = i32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int c = 0; c < CTW; ++c)            // the first K-step starts from a literal zero: no accumulator clearing
+                acc[pt][c] = mma_step<T>(wreg[c][ks], b, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pt][c]);
+        });
+    });
+}
+
+
+template <int C, int WM, int WN, int M, int TC, int KI, int OCC, bool POST>
+__global__ __launch_bounds__(WM * WN * 64, OCC)
+void conv1d_pair_kernel(const PairParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int EPC = 8;
+    constexpr int CH = C / EPC;
+    constexpr int PIXB = C * 2;
+    constexpr int NW = WM * WN;
+    constexpr int NT = NW * 64;
+    constexpr int CT = C / 16;
+    constexpr int CTW = CT / WN;
+    constexpr int PTW = (M / 16) / WM;
+    constexpr int KS = (3 * CH + 3) / 4;
+    constexpr int R = M / TC;
+    constexpr int RS = TC + 2;
+    constexpr int TB = TC / 16;
+    constexpr int BUFB = KI * NW * 1024;
+    constexpr int MIDB = R * RS * PIXB;
+    constexpr int NS = (M * CH) / NT;
+    constexpr int NCL = CH >= 4 ? (CH < 16 ? CH : 16) / 4 : 1;
+    constexpr int NLB1 = CH >= 4 ? NCL : KS;
+    constexpr int NLB2 = CH >= 4 ? 3 * NCL : KS;
+    static_assert(CT % WN == 0 && (M / 16) % WM == 0 && M % TC == 0, "tile split");
+    static_assert((M * CH) % NT == 0 && M * PIXB <= BUFB, "epilogue staging");
+    static_assert((R + 2) * TC * CH <= KI * NW * 64, "input tile fits the DMA plan");
+    static_assert(WM == 1 || TB == 1, "wave row split needs 16-column tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MID = 2 * BUFB;                      // byte offset of the intermediate rows
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int q = lane >> 4, r16 = lane & 15;
+
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((const char*)p.x - p.pad, (p.dbg & 1) ? 0u : p.bytes + p.pad);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y, (p.dbg & 2) ? 0u : p.bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.res ? p.res : p.x, p.bytes);
+
+    i32x4 wA[CTW][KS], wB[CTW][KS];
+    f32x4 sA[CTW], tA[CTW], sB[CTW], tB[CTW];
+    {
+        const i32x4* pa = (const i32x4*)p.wA;
+        const i32x4* pb = (const i32x4*)p.wB;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                wA[c][ks] = pa[((wn * CTW + c) * KS + ks) * 64 + lane];
+                wB[c][ks] = pb[((wn * CTW + c) * KS + ks) * 64 + lane];
+            }
+            const int co = (wn * CTW + c) * 16 + q * 4;
+            sA[c] = p.scaleA ? *(const f32x4*)(p.scaleA + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+            tA[c] = p.shiftA ? *(const f32x4*)(p.shiftA + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+            sB[c] = p.scaleB ? *(const f32x4*)(p.scaleB + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+            tB[c] = p.shiftB ? *(const f32x4*)(p.shiftB + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // ---- launch-invariant per-lane addressing
+    uint32_t in_rel[KI];                 // DMA source offset relative to the tile's input origin
+    int in_uj[KI];                       // (u << 16) | j of that slot; u = 255 for slots past the tile
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+        const int id = (k * NW + wave) * 64 + lane;
+        const int pix = id / CH, slot = id % CH;
+        const int u = pix / TC, j = pix % TC;
+        in_rel[k] = (uint32_t)((u * p.W + j) * p.d) * PIXB + swz<PIXB>(pix, slot) * 16;
+        in_uj[k] = ((u < R + 2 ? u : 255) << 16) | j;
+    }
+    int lb1[NLB1], lb2[NLB2];            // B-fragment read offsets: GEMM 1 (without the buffer offset), GEMM 2
+    if constexpr (CH >= 4) {
+#pragma unroll
+        for (int cl = 0; cl < NCL; ++cl) lb1[cl] = ((wm * PTW) * 16 + r16) * PIXB + swz<PIXB>(r16, cl * 4 + q) * 16;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int cl = 0; cl < NCL; ++cl)
+                lb2[tap * NCL + cl] = MID + (wm * PTW) * RS * PIXB + (r16 + tap) * PIXB + swz<PIXB>(r16 + tap, cl * 4 + q) * 16;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int gi = ks * 4 + q;
+            const int tap = gi / CH < 2 ? gi / CH : 2;
+            lb1[ks] = ((wm * PTW) * 16 + tap * TC + r16) * PIXB + swz<PIXB>(r16, gi % CH) * 16;
+            lb2[ks] = MID + (wm * PTW) * RS * PIXB + (r16 + tap) * PIXB + swz<PIXB>(r16 + tap, gi % CH) * 16;
+        }
+    }
+    int mid_w[CTW], stg_w[CTW];          // accumulator write offsets: intermediate rows / staging (pixel tile 0 of this wave)
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int chunk = (wn * CTW + c) * 2 + (q >> 1);
+        const int s = r16 + 1;
+        mid_w[c] = MID + ((wm * PTW / TB) * RS + s) * PIXB + swz<PIXB>(s, chunk) * 16 + (q & 1) * 8;
+        stg_w[c] = ((wm * PTW) * 16 + r16) * PIXB + swz<PIXB>(r16, chunk) * 16 + (q & 1) * 8;
+    }
+    int rb_lds[NS], out_ij[NS];          // read-back: LDS offset, (i << 16) | j, global offset relative to the tile's output origin
+    uint32_t out_rel[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int cid = tid + s * NT;
+        const int m = cid / CH, chunk = cid % CH;
+        const int i = m / TC, j = m % TC;
+        rb_lds[s] = m * PIXB + swz<PIXB>(m, chunk) * 16;
+        out_ij[s] = (i << 16) | j;
+        out_rel[s] = (uint32_t)((i * p.W + j) * p.d) * PIXB + chunk * 16;
+    }
+
+    // Pin everything loaded or computed above: a wait for it placed at its first use inside the loop
+    // would drain the DMA prefetch, and rematerialising it would cost the VALU work it is here to save.
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            tie_reg(wA[c][ks]);
+            tie_reg(wB[c][ks]);
+        }
+        asm volatile("" : "+v"(sA[c]), "+v"(tA[c]), "+v"(sB[c]), "+v"(tB[c]), "+v"(mid_w[c]), "+v"(stg_w[c]));
+    }
+#pragma unroll
+    for (int k = 0; k < KI; ++k) asm volatile("" : "+v"(in_rel[k]), "+v"(in_uj[k]));
+#pragma unroll
+    for (int i = 0; i < NLB1; ++i) asm volatile("" : "+v"(lb1[i]));
+#pragma unroll
+    for (int i = 0; i < NLB2; ++i) asm volatile("" : "+v"(lb2[i]));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(rb_lds[s]), "+v"(out_ij[s]), "+v"(out_rel[s]));
+
+    // intermediate rows start as zeros; only slots 1..TC of each row are ever written
+    for (int o = tid * 16; o < MIDB; o += NT * 16) *(i32x4*)(smem + MID + o) = i32x4{0, 0, 0, 0};
+
+    const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();      // max(v, floor_v): ReLU or identity without a select
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    PairGeo g = pair_geo<C, R, TC>(p, tile);
+    PairGeo g1 = pair_geo<C, R, TC>(p, tile + G);
+    pair_dma<KI, NW>(rs_x, smem, in_rel, in_uj, g, wave);
+    pair_dma<KI, NW>(rs_x, smem + BUFB, in_rel, in_uj, g1, wave);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");
+    ERF_LDS_BARRIER();
+
+    int cur = 0;
+    for (; tile < p.ntiles; tile += G, cur ^= 1) {
+        const int boff = cur * BUFB;
+
+        // ---------------- GEMM 1: 3x1 over the input tile
+        int lb[NLB1];
+#pragma unroll
+        for (int i = 0; i < NLB1; ++i) lb[i] = lb1[i] + boff;
+        f32x4 acc[PTW][CTW];
+        if (p.dbg & 4) {
+#pragma unroll
+            for (int pt = 0; pt < PTW; ++pt)
+#pragma unroll
+                for (int c = 0; c < CTW; ++c) acc[pt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            mfma_phase<C, TC, PTW, CTW, ImmIn>(lb, wA, acc, q);
+        }
+
+        // ---------------- intermediate = relu(sA * acc + tA) -> LDS rows (zero right of the image)
+#pragma unroll
+        for (int pt = 0; pt < PTW; ++pt) {
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                f32x4 v = acc[pt][c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sA[c][e] + tA[c][e], 0.f);
+                *(i32x2*)(smem + mid_w[c] + ((pt / TB) * RS + (pt % TB) * 16) * PIXB) = pack_bf16x4(v);
+            }
+        }
+        if (g.jhi < TC) {                             // wave-uniform and rare: tiles at the right image edge
+#pragma unroll
+            for (int pt = 0; pt < PTW; ++pt) {
+                if ((pt % TB) * 16 + r16 >= g.jhi) {  // WM == 1 whenever TB > 1
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c) *(i32x2*)(smem + mid_w[c] + ((pt / TB) * RS + (pt % TB) * 16) * PIXB) = i32x2{0, 0};
+                }
+            }
+        }
+        ERF_LDS_BARRIER();                 // intermediate complete; input tile no longer read
+
+        // ---------------- GEMM 2: 1x3 over the intermediate rows
+        if (!(p.dbg & 4)) mfma_phase<C, TC, PTW, CTW, ImmMid>(lb2, wB, acc, q);
+
+        // ---------------- accumulators -> LDS as [pixel][C] bf16 (in the consumed input buffer)
+#pragma unroll
+        for (int pt = 0; pt < PTW; ++pt) {
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                f32x4 v = acc[pt][c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v[e] * sB[c][e] + tB[c][e];
+                    if constexpr (!POST) v[e] = fmaxf(v[e], floor_v);
+                }
+                *(i32x2*)(smem + boff + stg_w[c] + pt * 16 * PIXB) = pack_bf16x4(v);
+            }
+        }
+        ERF_LDS_BARRIER();                 // staging complete; intermediate no longer read
+
+        // ---------------- coalesced read-back (+ residual, ReLU)
+        i32x4 outv[NS];
+        uint32_t ooff[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = out_ij[s] >> 16, j = out_ij[s] & 0xFFFF;
+            const bool ok = i < g.ihi && j >= g.jlo && j < g.jho;
+            ooff[s] = ok ? out_rel[s] : ERF_OOB;
+            outv[s] = *(const i32x4*)(smem + boff + rb_lds[s]);
+        }
+        if constexpr (POST) {
+            u32x4 rv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) rv[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ooff[s], g.out_soff, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float f[8], r[8];
+                ChunkOps<T>::unpack(outv[s], f);
+                ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, rv[s]), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e] + r[e], floor_v);
+                outv[s] = ChunkOps<T>::pack(f);
+            }
+        }
+        ERF_LDS_BARRIER();                 // staging consumed: the buffer may take tile k+2
+
+        const uint32_t out_soff = g.out_soff;
+        g = g1;
+        g1 = pair_geo<C, R, TC>(p, tile + 2 * G);
+        pair_dma<KI, NW>(rs_x, smem + boff, in_rel, in_uj, g1, wave);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");      // this wave's share of tile k+1 has landed
+#pragma unroll
+        for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[s]), rs_y, ooff[s], out_soff, 0);
+        asm volatile("s_barrier" ::: "memory");                          // ... and everyone else's
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
+#endif
+}
+
+template <int C, int WM, int WN, int M, int TC, int KI, int OCC, bool POST>
+static void launch_kernel(size_t lds, int grid, hipStream_t stream, const PairParams& p) {
+    auto kern = conv1d_pair_kernel<C, WM, WN, M, TC, KI, OCC, POST>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, stream, p);
+}
+
+template <int C, int WM, int WN, int M, int TC, int KI>
+static int launch_pair(PairParams p, hipStream_t stream) {
+    constexpr int NW = WM * WN;
+    constexpr int R = M / TC;
+    constexpr int PIXB = C * 2;
+    constexpr size_t lds = 2 * (size_t)KI * NW * 1024 + (size_t)R * (TC + 2) * PIXB;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    constexpr int OCC = (lds * 2 <= 160 * 1024 && NW <= 4) ? 2 : 1;
+    const int nh = (p.H + p.d - 1) / p.d, nw = (p.W + p.d - 1) / p.d;      // lattice points per residue (max)
+    p.CA = (nh + R - 1) / R;
+    p.CB = nw <= 2 ? 1 : (nw - 2 + TC - 3) / (TC - 2);
+    const long long nt = (long long)p.N * p.d * p.d * p.CA * p.CB;
+    if (nt > 0x1FFFFFFF) return ERF_EUNSUPPORTED;
+    p.ntiles = (int)nt;
+    p.fCB = make_fastdiv(p.CB); p.fCA = make_fastdiv(p.CA); p.fD = make_fastdiv(p.d);
+    const long long bytes = (long long)p.N * p.H * p.W * PIXB, pad = (long long)p.d * p.W * PIXB;
+    // 32-bit offsets: whole tensor plus one tile's reach below 2 GiB (bit 31 marks masked lanes)
+    if (bytes + pad + (long long)(R + 2) * pad >= 0x7FFFFFFFLL) return ERF_EUNSUPPORTED;
+    p.bytes = (uint32_t)bytes; p.pad = (uint32_t)pad;
+    int grid = 256 * OCC;
+    if (grid > p.ntiles) grid = p.ntiles;
+    if (p.res) launch_kernel<C, WM, WN, M, TC, KI, OCC, true>(lds, grid, stream, p);
+    else launch_kernel<C, WM, WN, M, TC, KI, OCC, false>(lds, grid, stream, p);
+    return erf_check_launch();
+}
+
+// Lattice-tile cost model: useful outputs / computed outputs for a TC-column tiling.
+static double pair_utilization(int H, int W, int d, int R, int TC) {
+    const int nh = (H + d - 1) / d, nw = (W + d - 1) / d;
+    const int CA = (nh + R - 1) / R;
+    const int CB = nw <= 2 ? 1 : (nw - 2 + TC - 3) / (TC - 2);
+    return (double)nh * nw / ((double)CA * R * CB * TC);
+}
+
+int conv1d_pair_launch(const void* x, void* y, const void* packedA, const void* packedB, const float* scaleA, const float* shiftA,
+                       const float* scaleB, const float* shiftB, const void* residual, int dtype, int N, int H, int W, int C,
+                       int dilation, int relu, hipStream_t stream) {
+    if (dtype != 1) return ERF_EUNSUPPORTED;
+    if ((long long)N * H * W >= (1LL << 31)) return ERF_EUNSUPPORTED;
+    PairParams p{};
+    p.x = (const T*)x; p.y = (T*)y; p.wA = packedA; p.wB = packedB;
+    p.scaleA = scaleA; p.shiftA = shiftA; p.scaleB = scaleB; p.shiftB = shiftB; p.res = (const T*)residual;
+    p.d = dilation; p.relu = relu; p.N = N; p.H = H; p.W = W;
+    static const int dbg = getenv("ERF_PAIR_DBG") ? atoi(getenv("ERF_PAIR_DBG")) : 0;
+    p.dbg = dbg;
+    // Sparse lattices (few points per residue class) waste most of a tile: leave those to two single launches.
+    if (C == 128) {
+        const double u16 = pair_utilization(H, W, dilation, 8, 16), u32 = pair_utilization(H, W, dilation, 4, 32);
+        if (u16 < 0.6 && u32 < 0.6) return ERF_EUNSUPPORTED;
+        if (u32 > u16 * 1.1) return launch_pair<128, 1, 8, 128, 32, 6>(p, stream);
+        return launch_pair<128, 1, 8, 128, 16, 5>(p, stream);
+    }
+    if (C == 64) {
+        if (pair_utilization(H, W, dilation, 8, 16) < 0.6) return ERF_EUNSUPPORTED;
+        return launch_pair<64, 2, 2, 128, 16, 5>(p, stream);
+    }
+    if (C == 16) {
+        if (pair_utilization(H, W, dilation, 32, 16) < 0.6) return ERF_EUNSUPPORTED;
+        return launch_pair<16, 4, 1, 512, 16, 5>(p, stream);
+    }
+    return ERF_EUNSUPPORTED;
+}

@@ -122,6 +122,20 @@ def conv1d(x, packed, scale, shift, residual, axis: int, dilation: int, relu: bo
     return y
 
 
+def conv1d_pair(x, packed_a, shift_a, packed_b, scale_b, shift_b, residual, dilation: int, relu: bool = True, out=None):
+    """conv3x1 -> +shift_a -> ReLU -> conv1x3 -> scale_b/shift_b (+ residual) -> ReLU in one launch.
+    Returns None when the library does not take the shape (the caller then issues the two convolutions)."""
+    n, h, w, c = x.shape
+    y = torch.empty_like(x) if out is None else out
+    rc = query("erf_conv1d_pair", x.data_ptr(), y.data_ptr(), packed_a.data_ptr(), packed_b.data_ptr(), 0, _p(shift_a),
+               _p(scale_b), _p(shift_b), _p(residual), dt(x), n, h, w, c, dilation, int(relu), _stream())
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError(f"erf_conv1d_pair failed with status {rc}")
+    return y
+
+
 def downsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None):
     n, h, w, cin = x.shape
     y = torch.empty((n, h // 2, w // 2, cout), dtype=x.dtype, device=x.device) if out is None else out

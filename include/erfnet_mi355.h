@@ -54,6 +54,16 @@ int erf_conv1d_factorized(const void* x, void* y, const void* packed, const floa
                           const void* residual, int dtype, int N, int H, int W, int C, int axis, int dilation,
                           int relu, void* stream);
 
+/* One half of non_bottleneck_1d.forward in a single launch (inference; train/erfnet.py:58-62 or
+ * :64-74 with BatchNorm in eval mode folded into scale_b/shift_b):
+ *     y = act( scale_b * conv1x3_d( relu( scale_a * conv3x1_d(x) + shift_a ) ) + shift_b (+ residual) )
+ * packed_a / packed_b: mode-0 packed weights of the 3x1 and the 1x3 convolution.  bf16 only.
+ * Returns ERF_EUNSUPPORTED (-2) without launching for shapes it does not take (fp32, or a dilation
+ * that leaves too few pixels per residue class): issue two erf_conv1d_factorized calls then. */
+int erf_conv1d_pair(const void* x, void* y, const void* packed_a, const void* packed_b, const float* scale_a,
+                    const float* shift_a, const float* scale_b, const float* shift_b, const void* residual, int dtype,
+                    int N, int H, int W, int C, int dilation, int relu, void* stream);
+
 /* ---- DownsamplerBlock, train/erfnet.py:11-22 ------------------------------------------
  * y[..., :Cout-Cin] = conv3x3 s2 p1 (x), y[..., Cout-Cin:] = maxpool2x2 (x), then
  * y = act(scale * y + shift) over all Cout channels (concat happens on write).

@@ -56,6 +56,55 @@ def test_conv1d_factorized(dtype, tol, c, shape, axis, dil):
     assert rel_err(_back(y2), ref2) <= tol
 
 
+@pytest.mark.parametrize("c,shape,dil", [
+    (128, (2, 128, 64, 128), 1), (128, (1, 128, 64, 128), 2), (128, (1, 128, 64, 128), 4), (128, (2, 128, 64, 128), 8),
+    (128, (1, 128, 37, 53), 2), (128, (1, 128, 23, 70), 1), (128, (1, 128, 45, 62), 4),
+    (64, (1, 64, 128, 256), 1), (64, (2, 64, 19, 41), 1), (64, (1, 64, 33, 30), 2),
+    (16, (1, 16, 256, 512), 1), (16, (2, 16, 50, 70), 1), (16, (1, 16, 61, 30), 1),
+])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv1d_pair_equals_two_launches_and_reference(c, shape, dil, with_res):
+    """Fused conv3x1 -> ReLU -> conv1x3 launch (bf16): against the two single launches it replaces (same
+    bf16 rounding points, so within one bf16 ulp) and against the fp32 torch reference of the same ops."""
+    from erfnet_pytorch_amd import ops
+    seed = 300 + c + dil
+    x = activations(shape, seed) - 0.3
+    wa = S.fill_tensor("p.a.weight", (c, c, 3, 1), salt=seed)
+    wb = S.fill_tensor("p.b.weight", (c, c, 1, 3), salt=seed)
+    ba = S.fill_tensor("p.a.bias", (c,), salt=seed)
+    bb = S.fill_tensor("p.b.bias", (c,), salt=seed)
+    sb = S.fill_tensor("p.bn.weight", (c,), salt=seed)
+    res = activations(shape, seed + 1) if with_res else None
+    mid = F.relu(F.conv2d(x, wa, ba, padding=(dil, 0), dilation=(dil, 1)))
+    ref = F.conv2d(mid, wb, None, padding=(0, dil), dilation=(1, dil)) * sb[None, :, None, None] + bb[None, :, None, None]
+    ref = F.relu(ref + res) if with_res else F.relu(ref)
+    code = ops.dt(torch.empty(0, dtype=torch.bfloat16))
+    pa, pb = ops.pack_conv1d(wa.to(_dev()), code), ops.pack_conv1d(wb.to(_dev()), code)
+    xd = _nhwc(x, torch.bfloat16)
+    rd = _nhwc(res, torch.bfloat16) if with_res else None
+    y = ops.conv1d_pair(xd, pa, ba.to(_dev()), pb, sb.to(_dev()), bb.to(_dev()), rd, dil, True)
+    assert y is not None, "shape should be taken by the fused kernel"
+    m = ops.conv1d(xd, pa, None, ba.to(_dev()), None, 0, dil, True)
+    y2 = ops.conv1d(m, pb, sb.to(_dev()), bb.to(_dev()), rd, 1, dil, True)
+    torch.cuda.synchronize()
+    assert rel_err(_back(y), ref) <= BF16_TOL
+    diff = (y.float() - y2.float()).abs()
+    ulp = y2.float().abs().clamp_min(1e-2) * 2.0 ** -7
+    assert bool((diff <= ulp).all()), f"max diff {diff.max().item()} at {(diff / ulp).max().item()} ulp"
+
+
+def test_conv1d_pair_declines_sparse_lattices_and_fp32():
+    from erfnet_pytorch_amd import ops
+    code = ops.dt(torch.empty(0, dtype=torch.bfloat16))
+    w = S.fill_tensor("p.a.weight", (128, 128, 3, 1), salt=1).to(_dev())
+    pk = ops.pack_conv1d(w, code)
+    b = torch.zeros(128, device=_dev())
+    x = torch.zeros(1, 64, 128, 128, device=_dev(), dtype=torch.bfloat16)
+    assert ops.conv1d_pair(x, pk, b, pk, None, b, None, 16, True) is None            # 4 x 8 points per residue class
+    pk32 = ops.pack_conv1d(w, ops.dt(torch.empty(0)))
+    assert ops.conv1d_pair(x.float(), pk32, b, pk32, None, b, None, 1, True) is None
+
+
 def _block_tags():
     g = load("g2_blocks.npz")
     return sorted({k.split("__prefix")[0] for k in g.files if k.endswith("__prefix")})
