@@ -3,14 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N = 1 (default): BASELINE.json configs[1] -- ERFNet(20) inference, batch 16, bf16 activations
-  with fp32 accumulation, 3x512x1024 synthetic images resident in HBM, fused arg-max and the
-  iouEval confusion histogram; one step = one batch through the whole pipeline, replayed from a
-  HIP graph.  The line also carries the roofline of the dominant kernel (measured here with
-  events on the launch stream) and the CPU baseline (the oracle's fp32 forward, b=1, timed on
-  this box's host cores with the eval_forwardTime protocol).
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): BASELINE.json configs[2] --
-  data-parallel training, batch 6 per GPU, weighted cross-entropy, Adam; see `run_train`.
+Headline (`value`), every N: BASELINE.json configs[1] -- ERFNet(20) inference, batch 16 per GPU, bf16
+  activations with fp32 accumulation, 3x512x1024 synthetic images resident in HBM, fused arg-max and
+  the iouEval confusion histogram; one step = one batch through the whole pipeline, replayed from a
+  HIP graph.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own
+  shard of images -- the path has no exchange step, so there is no collective in it ("weak" scaling).
+  The line also carries the roofline of the dominant kernel (measured here with events on the launch
+  stream) and, at N = 1, the CPU baseline (the oracle's fp32 forward, b=1, timed on this box's host
+  cores with the eval_forwardTime protocol).
+"training" object, every N: BASELINE.json configs[2] -- data-parallel training, batch 6 per GPU,
+  weighted cross-entropy, Adam, gradient all-reduce over RCCL inside the timed region; see
+  `trainer.bench_train`.  `--mode train` makes that leg the headline instead.
 Rank 0 prints exactly one JSON line.
 """
 from __future__ import annotations
@@ -46,6 +49,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="auto mode: skip the training leg")
+    ap.add_argument("--train-batch", type=int, default=6)
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-warmup", type=int, default=3)
     return ap.parse_args()
 
 
@@ -111,26 +118,64 @@ def cpu_baseline(height, width, budget_s=20.0):
             "sample": f"oracle ERFNet(20) fp32 forward b=1 3x{height}x{width}, mean of {len(times)} iterations after 1 warm-up"}
 
 
+def measured_traffic(kernel_prefix, pixels):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, mean over the kernel's
+    variants); only quoted when this run has the shape the counters were collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or pixels != 16 * 128 * 256:
+        return None
+    vals = [v for k, v in json.load(open(path)).items() if kernel_prefix in k]
+    return sum(vals) / len(vals) if vals else None
+
+
 def roofline_infer(model, x, dtype_name):
-    """Time the dominant kernel (factorized conv, C=128) alone: every 128-channel 3x1/1x3 launch
-    of one forward (32 launches, dilations 1..16) bracketed by events on the launch stream."""
+    """Time the dominant kernel of one forward alone, with events on the launch stream.
+
+    bf16: the fused conv3x1->conv1x3 pair kernel on the 64-channel blocks (14 launches per forward, the
+    largest share of the step).  Its arithmetic intensity (2*2*3*C*C flop per pixel over 2..3 x C*2 bytes
+    = 154..192 flop/B) is below the MI355X ridge (2500 TFLOP/s / 8 TB/s = 312 flop/B): HBM-bound.
+    Algorithmic bytes per launch = input tensor + output tensor (+ the residual tensor for the second
+    pair of a block), each N*H/4*W/4*64*2 bytes.
+    fp32: the single factorized convolution on the 128-channel blocks (MFMA-bound, 32 launches)."""
     from erfnet_pytorch_amd import ops
     from erfnet_pytorch_amd._lib import AXIS_H, AXIS_W
     n, _, h, w = x.shape
-    hh, ww, c = h // 8, w // 8, 128
-    tdt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-    feat = torch.randn(n, hh, ww, c, device=x.device).to(tdt)
-    out = torch.empty_like(feat)
-    blocks = [m for m in model.encoder.layers if getattr(m, "chann", 0) == 128]
-    plan = []
-    for blk in blocks:
-        cc = blk._cached(ops.dt(feat))
-        d = blk.dilated
-        plan += [(cc["w1"], None, cc["t1"], None, AXIS_H, 1), (cc["w2"], cc["s2"], cc["t2"], None, AXIS_W, 1),
-                 (cc["w3"], None, cc["t3"], None, AXIS_H, d), (cc["w4"], cc["s4"], cc["t4"], feat, AXIS_W, d)]
-    def run():
-        for (wp, s, t, r, ax, d) in plan:
-            ops.conv1d(feat, wp, s, t, r, ax, d, True, out=out)
+    if dtype_name == "bf16":
+        hh, ww, c = h // 4, w // 4, 64
+        feat = torch.randn(n, hh, ww, c, device=x.device).to(torch.bfloat16)
+        mid, out = torch.empty_like(feat), torch.empty_like(feat)
+        blocks = [m for m in list(model.encoder.layers) + list(model.decoder.layers) if getattr(m, "chann", 0) == 64]
+        plan = []
+        for blk in blocks:
+            cc = blk._cached(ops.dt(feat))
+            plan += [(feat, mid, cc["w1"], cc["t1"], cc["w2"], cc["s2"], cc["t2"], None, 1),
+                     (mid, out, cc["w3"], cc["t3"], cc["w4"], cc["s4"], cc["t4"], feat, blk.dilated)]
+        def run():
+            for (src, dst, wa, ta, wb, sb, tb, r, d) in plan:
+                if ops.conv1d_pair(src, wa, ta, wb, sb, tb, r, d, True, out=dst) is None:
+                    raise RuntimeError("pair kernel declined the benchmark shape")
+        tensor_bytes = feat.numel() * 2
+        bytes_per_launch = sum(tensor_bytes * (3 if r is not None else 2) for (*_, r, _d) in plan) / len(plan)
+        flop = 2 * 2.0 * 3 * c * c * n * hh * ww
+        name = "conv1d_pair_kernel<64> (fused conv3x1+conv1x3, 64-channel blocks)"
+    else:
+        hh, ww, c = h // 8, w // 8, 128
+        feat = torch.randn(n, hh, ww, c, device=x.device)
+        out = torch.empty_like(feat)
+        blocks = [m for m in model.encoder.layers if getattr(m, "chann", 0) == 128]
+        plan = []
+        for blk in blocks:
+            cc = blk._cached(ops.dt(feat))
+            d = blk.dilated
+            plan += [(cc["w1"], None, cc["t1"], None, AXIS_H, 1), (cc["w2"], cc["s2"], cc["t2"], None, AXIS_W, 1),
+                     (cc["w3"], None, cc["t3"], None, AXIS_H, d), (cc["w4"], cc["s4"], cc["t4"], feat, AXIS_W, d)]
+        def run():
+            for (wp, s_, t_, r, ax, d) in plan:
+                ops.conv1d(feat, wp, s_, t_, r, ax, d, True, out=out)
+        bytes_per_launch = feat.numel() * 4 * 2.25
+        flop = 2.0 * 3 * c * c * n * hh * ww
+        name = "conv1d_dma_kernel<float,128> (factorized conv, 128-channel blocks)"
     run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -141,11 +186,14 @@ def roofline_infer(model, x, dtype_name):
     e1.record()
     torch.cuda.synchronize()
     avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * len(plan))
-    flop = 2.0 * 3 * c * c * n * hh * ww
+    if dtype_name == "bf16":
+        achieved = bytes_per_launch / avg_s / 1e9
+        return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": achieved / PEAK_HBM_GBS, "traffic": measured_traffic("conv1d_pair_kernel<64,", n * hh * ww), "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
+                "bytes_per_launch": bytes_per_launch, "flop_per_launch": flop, "mfma_tflops": flop / avg_s / 1e12}
     achieved = flop / avg_s / 1e12
-    peak = PEAK_BF16_TFLOPS if dtype_name == "bf16" else PEAK_F32_TFLOPS
-    return {"bound": "mfma", "kernel": "conv1d_factorized C=128", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
+    return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
             "flop_per_launch": flop}
 
 
@@ -190,7 +238,7 @@ def run_infer(args, world, rank, dev):
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"ERFNet(20) inference + fused argmax + iouEval histogram, batch {batch}/GPU, "
-                               f"3x{args.height}x{args.width}, {'replicas only' if world > 1 else 'single GPU'}",
+                               f"3x{args.height}x{args.width}, {'independent shards per rank' if world > 1 else 'single GPU'}",
                    "hip_graph": graph is not None, "synthetic_miou": miou},
     }
     if rank == 0:
@@ -212,10 +260,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and the package has no CPU path")
     world, rank, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
-    mode = args.mode
-    if mode == "auto":
-        mode = "infer" if world == 1 else "train"
-    res = run_infer(args, world, rank, dev) if mode == "infer" else run_train(args, world, rank, dev)
+    # auto: the headline value is the inference pipeline at every N (independent shards per rank, no
+    # data-path collective), and the data-parallel training step is measured in the same run and
+    # reported under "training" (its own steps/warmup, RCCL gradient all-reduce inside the timed region).
+    if args.mode == "train":
+        res = run_train(args, world, rank, dev)
+    else:
+        res = run_infer(args, world, rank, dev)
+        if args.mode == "auto" and not args.no_train:
+            targs = argparse.Namespace(**vars(args))
+            targs.batch, targs.steps, targs.warmup = args.train_batch, args.train_steps, args.train_warmup
+            tr = run_train(targs, world, rank, dev)
+            res["training"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "model_tflops")}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.height, args.width)

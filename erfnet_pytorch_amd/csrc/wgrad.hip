@@ -12,6 +12,7 @@
 // order and scatters them into the torch weight layout (no atomics: bit-reproducible).
 #include "common.cuh"
 #include "train.cuh"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -183,9 +184,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 static void plan(long long P, int* nwg, int* spw) {
+    static const int target = getenv("ERF_WGRAD_WGS") ? atoi(getenv("ERF_WGRAD_WGS")) : 512;
+    static const int smin = getenv("ERF_WGRAD_SMIN") ? atoi(getenv("ERF_WGRAD_SMIN")) : 8;
     const long long steps = (P + 31) / 32;
-    long long s = (steps + 127) / 128;
-    if (s < 16) s = 16;
+    long long s = (steps + target - 1) / target;
+    if (s < smin) s = smin;
     *spw = (int)s;
     *nwg = (int)((steps + s - 1) / s);
 }
