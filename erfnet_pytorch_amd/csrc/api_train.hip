@@ -279,6 +279,8 @@ int erf_conv1d_wgrad(const void* x, const void* dz, float* dw, int dtype, int N,
     PackParams m{};
     m.cin = C; m.cout_virtual = C; m.ncp = NO_PHASES; m.nc_valid = C; m.s_co = 3LL * C; m.s_ci = 3; m.ntaps = 3;
     m.toff[0] = 0; m.toff[1] = 1; m.toff[2] = 2;
+    const int rc = wgrad1d_launch(x, dz, dw, dtype, N, H, W, C, axis, dilation, m, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc != ERF_EUNSUPPORTED) return rc;
     return wgrad_launch(g, dz, C, 0, C, C, &m, dw, (float*)workspace, workspace_bytes, dtype, (hipStream_t)stream);
 }
 

@@ -46,3 +46,10 @@ int image_pad_launch(const void* x, int src_dtype, void* out, int dtype, int N, 
 size_t wgrad_workspace_bytes(int rows, int cin, int max_taps_per_phase, long long base_pixels);
 int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, int rows, int cin, const PackParams* maps,
                  float* dw, float* workspace, size_t workspace_bytes, int dtype, hipStream_t stream);
+
+// Sum of `nwg` fp32 partial tiles [rows_pad][ncols_pad] (column = tap*cin + ci), scattered into torch weight layout.
+int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_pad, int cin, const PackParams& m, float* dw,
+                        hipStream_t stream);
+// Factorized-convolution weight gradient on lattice tiles (bf16).  ERF_EUNSUPPORTED: use wgrad_launch.
+int wgrad1d_launch(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis, int dilation,
+                   const PackParams& map, float* workspace, size_t workspace_bytes, hipStream_t stream);

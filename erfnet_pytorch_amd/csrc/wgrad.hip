@@ -183,6 +183,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[(long long)cls * m.s_co + (long long)phase * m.s_phase + (long long)ci * m.s_ci + m.toff[tap]] = (float)s;
 }
 
+int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_pad, int cin, const PackParams& m, float* dw,
+                        hipStream_t stream) {
+    const int total = m.cout_virtual * m.ntaps * cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, nwg, rows_pad, ncols_pad, cin, m, dw);
+    return erf_check_launch();
+}
+
 static void plan(long long P, int* nwg, int* spw) {
     static const int target = getenv("ERF_WGRAD_WGS") ? atoi(getenv("ERF_WGRAD_WGS")) : 512;
     static const int smin = getenv("ERF_WGRAD_SMIN") ? atoi(getenv("ERF_WGRAD_SMIN")) : 8;
