@@ -83,11 +83,24 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     const int nparts = FIN_THREADS / C;
     const int c = threadIdx.x % C, part = threadIdx.x / C;
     double a = 0, b = 0;
-    if (part < nparts)
-        for (int g = part; g < groups; g += nparts) {
-            a += partials[(long long)g * 2 * C + c];
-            b += partials[(long long)g * 2 * C + C + c];
+    if (part < nparts) {
+        // four independent chains keep the loads in flight; the order of the additions is fixed
+        double a4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0};
+        int g = part;
+        for (; g + 3 * nparts < groups; g += 4 * nparts) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a4[u] += partials[(long long)(g + u * nparts) * 2 * C + c];
+                b4[u] += partials[(long long)(g + u * nparts) * 2 * C + C + c];
+            }
         }
+        for (; g < groups; g += nparts) {
+            a4[0] += partials[(long long)g * 2 * C + c];
+            b4[0] += partials[(long long)g * 2 * C + C + c];
+        }
+        a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    }
     sh[threadIdx.x] = a;
     sh[FIN_THREADS + threadIdx.x] = b;
     __syncthreads();
@@ -407,7 +420,9 @@ int pool_bwd_launch(const void* x, const void* dz, void* dx, int dtype, int N, i
 // Weighted cross-entropy over NCHW logits (one thread per pixel, class planes read coalesced).
 // fwd: partial (sum w[t]*nll, sum w[t]) per block -> finalize writes {num, den, num/den}.
 // bwd: dlogits[c] = coefficient * w[t] * (softmax[c] - [c == t]), coefficient read from device memory.
-template <typename T, int BWD>
+// NC > 0: the class count is a compile-time constant and a pixel's logits are read once into registers
+// (NC independent loads in flight per thread); NC == 0: any class count, three passes over the planes.
+template <typename T, int BWD, int NC>
 __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ z, const long long* __restrict__ target,
                                                  const float* __restrict__ weight, int C, long long HW, long long total,
                                                  float* __restrict__ partials, const float* __restrict__ coef,
@@ -420,11 +435,38 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ z, const 
         const T* p = z + n * C * HW + hw;
         const long long t = target[idx];
         const bool valid = t >= 0 && t < C;
+        const float w = valid ? (weight ? weight[t] : 1.f) : 0.f;
+        if constexpr (NC > 0) {
+            float v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = Elem<T>::ld(p + c * HW);
+            float m = v[0];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) m = fmaxf(m, v[c]);
+            float se = 0.f, zt = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                zt = (c == t) ? v[c] : zt;
+                v[c] = __expf(v[c] - m);
+                se += v[c];
+            }
+            if (!BWD) {
+                if (valid) {
+                    acc_l += w * (m + __logf(se) - zt);
+                    acc_w += w;
+                }
+            } else {
+                const float inv = 1.f / se;
+                T* q = dz + n * C * HW + hw;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) Elem<T>::st(q + c * HW, k * w * (v[c] * inv - (c == t ? 1.f : 0.f)));
+            }
+            continue;
+        }
         float m = -INFINITY;
         for (int c = 0; c < C; ++c) m = fmaxf(m, Elem<T>::ld(p + c * HW));
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(p + c * HW) - m);
-        const float w = valid ? (weight ? weight[t] : 1.f) : 0.f;
         if (!BWD) {
             if (valid) {
                 const float zt = Elem<T>::ld(p + t * HW);
@@ -452,11 +494,12 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ z, const 
 }
 
 __global__ void ce_finalize_kernel(const float* __restrict__ partials, int groups, float* __restrict__ out) {
-    if (threadIdx.x == 0) {
-        double a = 0, b = 0;
-        for (int g = 0; g < groups; ++g) { a += partials[2 * g]; b += partials[2 * g + 1]; }
-        out[0] = (float)a; out[1] = (float)b; out[2] = (float)(a / b);
-    }
+    // 64 threads: lane l sums groups l, l + 64, ... in double, then a fixed-order butterfly
+    double a = 0, b = 0;
+    for (int g = threadIdx.x; g < groups; g += 64) { a += partials[2 * g]; b += partials[2 * g + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (threadIdx.x == 0) { out[0] = (float)a; out[1] = (float)b; out[2] = (float)(a / b); }
 }
 
 size_t ce_workspace_bytes() { return (size_t)RED_MAX_GROUPS * 2 * sizeof(float); }
@@ -467,12 +510,12 @@ int ce_fwd_launch(const void* z, int dtype, const long long* target, const float
     long long g = (total + 256 * 4 - 1) / (256 * 4);
     if (g > RED_MAX_GROUPS) g = RED_MAX_GROUPS;
     if (g < 1) g = 1;
-    if (dtype == 1)
-        hipLaunchKernelGGL((ce_kernel<bf16raw, 0>), dim3((unsigned)g), dim3(256), 0, stream, (const bf16raw*)z, target, weight,
-                           C, HW, total, partials, (const float*)nullptr, (bf16raw*)nullptr);
-    else
-        hipLaunchKernelGGL((ce_kernel<float, 0>), dim3((unsigned)g), dim3(256), 0, stream, (const float*)z, target, weight, C,
-                           HW, total, partials, (const float*)nullptr, (float*)nullptr);
+#define CE_FWD(TT, NCV)                                                                                                    \
+    hipLaunchKernelGGL((ce_kernel<TT, 0, NCV>), dim3((unsigned)g), dim3(256), 0, stream, (const TT*)z, target, weight, C, HW, \
+                       total, partials, (const float*)nullptr, (TT*)nullptr)
+    if (dtype == 1) { if (C == 20) CE_FWD(bf16raw, 20); else if (C == 6) CE_FWD(bf16raw, 6); else CE_FWD(bf16raw, 0); }
+    else { if (C == 20) CE_FWD(float, 20); else if (C == 6) CE_FWD(float, 6); else CE_FWD(float, 0); }
+#undef CE_FWD
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, (int)g, out);
     return erf_check_launch();
 }
@@ -480,12 +523,12 @@ int ce_fwd_launch(const void* z, int dtype, const long long* target, const float
 int ce_bwd_launch(const void* z, int dtype, const long long* target, const float* weight, int N, int C, long long HW,
                   const float* coef, void* dz, hipStream_t stream) {
     const long long total = (long long)N * HW;
-    if (dtype == 1)
-        hipLaunchKernelGGL((ce_kernel<bf16raw, 1>), dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16raw*)z, target,
-                           weight, C, HW, total, (float*)nullptr, coef, (bf16raw*)dz);
-    else
-        hipLaunchKernelGGL((ce_kernel<float, 1>), dim3(ew_grid(total)), dim3(256), 0, stream, (const float*)z, target, weight,
-                           C, HW, total, (float*)nullptr, coef, (float*)dz);
+#define CE_BWD(TT, NCV)                                                                                                      \
+    hipLaunchKernelGGL((ce_kernel<TT, 1, NCV>), dim3(ew_grid(total)), dim3(256), 0, stream, (const TT*)z, target, weight, C, HW, \
+                       total, (float*)nullptr, coef, (TT*)dz)
+    if (dtype == 1) { if (C == 20) CE_BWD(bf16raw, 20); else if (C == 6) CE_BWD(bf16raw, 6); else CE_BWD(bf16raw, 0); }
+    else { if (C == 20) CE_BWD(float, 20); else if (C == 6) CE_BWD(float, 6); else CE_BWD(float, 0); }
+#undef CE_BWD
     return erf_check_launch();
 }
 

@@ -161,32 +161,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // dW[map(row, tap, ci)] = sum_wg partial[wg][row][tap*CIN + ci]
+// Block = 32 consecutive elements x 8 slices of the workgroup range; every slice sums its partials in a
+// fixed order (four chains, so the loads overlap), the slices meet in LDS and are added in slice order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int rows_pad,
                                                            int ncols_pad, int cin, const PackParams m, float* __restrict__ dw) {
+    __shared__ double sh[8][32];
     const int total = m.cout_virtual * m.ntaps * cin;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int col = idx % (m.ntaps * cin), row = idx / (m.ntaps * cin);
-    const int tap = col / cin, ci = col % cin;
-    const int phase = row / m.ncp, cls = row % m.ncp;
-    if (cls >= m.nc_valid || (m.cin_valid && ci >= m.cin_valid)) return;
-    const long long stride = (long long)rows_pad * ncols_pad;
-    const float* src = partial + (long long)row * ncols_pad + col;
-    float s4[4] = {0.f, 0.f, 0.f, 0.f};                  // four independent chains keep the loads in flight
-    int g = 0;
-    for (; g + 4 <= nwg; g += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] += src[(g + u) * stride];
+    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    bool valid = idx < total;
+    int col = 0, row = 0, tap = 0, ci = 0, phase = 0, cls = 0;
+    if (valid) {
+        col = idx % (m.ntaps * cin); row = idx / (m.ntaps * cin);
+        tap = col / cin; ci = col % cin;
+        phase = row / m.ncp; cls = row % m.ncp;
+        valid = cls < m.nc_valid && !(m.cin_valid && ci >= m.cin_valid);
     }
-    for (; g < nwg; ++g) s4[0] += src[g * stride];
-    const double s = ((double)s4[0] + (double)s4[1]) + ((double)s4[2] + (double)s4[3]);
-    dw[(long long)cls * m.s_co + (long long)phase * m.s_phase + (long long)ci * m.s_ci + m.toff[tap]] = (float)s;
+    double acc = 0.0;
+    if (valid) {
+        const long long stride = (long long)rows_pad * ncols_pad;
+        const float* src = partial + (long long)row * ncols_pad + col;
+        const int per = (nwg + 7) / 8;
+        int g = sl * per;
+        const int g1 = g + per < nwg ? g + per : nwg;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (; g + 4 <= g1; g += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += src[(g + u) * stride];
+        }
+        for (; g < g1; ++g) s4[0] += src[g * stride];
+        acc = ((double)s4[0] + (double)s4[1]) + ((double)s4[2] + (double)s4[3]);
+    }
+    sh[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && valid) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += sh[k][e];
+        dw[(long long)cls * m.s_co + (long long)phase * m.s_phase + (long long)ci * m.s_ci + m.toff[tap]] = (float)s;
+    }
 }
 
 int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_pad, int cin, const PackParams& m, float* dw,
                         hipStream_t stream) {
     const int total = m.cout_virtual * m.ntaps * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, nwg, rows_pad, ncols_pad, cin, m, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, partial, nwg, rows_pad, ncols_pad, cin, m, dw);
     return erf_check_launch();
 }
 
@@ -273,7 +292,7 @@ int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, in
         if (rc) return rc;
         const PackParams& m = maps[ph];
         const int total = m.cout_virtual * m.ntaps * cin;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, workspace, nwg, cot * 16,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, workspace, nwg, cot * 16,
                            wp.ncols_pad, cin, m, dw);
         rc = erf_check_launch();
         if (rc) return rc;
