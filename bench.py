@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["auto", "infer", "train"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "infer", "train", "imagenet"], default="auto")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 inference, 6 training)")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
@@ -263,7 +263,10 @@ def main():
     # auto: the headline value is the inference pipeline at every N (independent shards per rank, no
     # data-path collective), and the data-parallel training step is measured in the same run and
     # reported under "training" (its own steps/warmup, RCCL gradient all-reduce inside the timed region).
-    if args.mode == "train":
+    if args.mode == "imagenet":
+        from erfnet_pytorch_amd import trainer
+        res = trainer.bench_imagenet(args, world, rank, dev, barrier, max_over_ranks)
+    elif args.mode == "train":
         res = run_train(args, world, rank, dev)
     else:
         res = run_infer(args, world, rank, dev)

@@ -45,6 +45,10 @@ SIGNATURES = {
     "erf_conv1d_packed_bytes": (c_size_t, [I, I]),
     "erf_conv1d_pack": (I, [P, P, I, I, I, P]),
     "erf_conv1d_factorized": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "erf_maxpool2_avgpool_fwd": (I, [P, I, P, I, I, I, I, P]),
+    "erf_maxpool2_avgpool_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "erf_linear_fwd": (I, [P, P, P, P, I, I, I, P]),
+    "erf_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
     "erf_conv1d_pair": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "erf_downsampler_packed_bytes": (c_size_t, [I, I, I]),
     "erf_downsampler_pack": (I, [P, P, I, I, I, P]),

@@ -90,6 +90,19 @@ def channel_sum(z, out=None):
     return out
 
 
+def pre_bn_bias_grad(dz, batch_stats, out=None):
+    """Gradient of a conv bias that feeds a BatchNorm directly.  With batch statistics the BatchNorm backward
+    removes the per-channel mean of its output gradient, so sum_p dz[p][c] is exactly zero in exact arithmetic
+    (the reference computes rounding noise around zero): write the analytic value and skip the pass over dz.
+    With frozen statistics (eval mode with gradients) the sum is a real gradient."""
+    if not batch_stats:
+        return channel_sum(dz, out)
+    c = dz.shape[-1]
+    if out is None:
+        return torch.zeros(c, device=dz.device)
+    return out.zero_()
+
+
 def conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation):
     n, h, w, c = dy.shape
     dx = torch.empty_like(dy)
@@ -179,7 +192,7 @@ class _NB1dFn(torch.autograd.Function):
         o = lambda name, shape: sk.out(name, shape, dev)
         dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True,
                                             dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
-        db4 = channel_sum(dz4, o("conv1x3_2.bias", (c,)))
+        db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)))
         dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
         dz3 = conv1d_dgrad(dz4, ops.pack_conv1d(w4, code, 1), a3, None, AXIS_W, d)
         db3 = channel_sum(dz3, o("conv3x1_2.bias", (c,)))
@@ -187,7 +200,7 @@ class _NB1dFn(torch.autograd.Function):
         da2 = conv1d_dgrad(dz3, ops.pack_conv1d(w3, code, 1), None, None, AXIS_H, d)
         dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
                                         dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
-        db2 = channel_sum(dz2, o("conv1x3_1.bias", (c,)))
+        db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)))
         dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
         dz1 = conv1d_dgrad(dz2, ops.pack_conv1d(w2, code, 1), a1, None, AXIS_W, 1)
         db1 = channel_sum(dz1, o("conv3x1_1.bias", (c,)))
@@ -230,7 +243,10 @@ class _DownFn(torch.autograd.Function):
         dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
                                            dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
         db = sk.out("conv.bias", (cc,), dev)
-        db.copy_(channel_sum(dz)[:cc])
+        if ctx.training:
+            db.zero_()                                   # analytic value, see pre_bn_bias_grad
+        else:
+            db.copy_(channel_sum(dz)[:cc])
         dw = sk.out("conv.weight", w.shape, dev)
         n, ho, wo, _ = z.shape
         if cin == 3:
@@ -282,7 +298,7 @@ class _UpFn(torch.autograd.Function):
         sk = _Sink(ctx.mod)
         dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
                                            dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
-        db = channel_sum(dz, sk.out("conv.bias", (cout,), dev))
+        db = pre_bn_bias_grad(dz, ctx.training, sk.out("conv.bias", (cout,), dev))
         dw = sk.out("conv.weight", w.shape, dev)
         nb = query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)
         ws = _ws(nb, dev)

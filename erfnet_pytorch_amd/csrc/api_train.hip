@@ -352,4 +352,26 @@ int erf_output_conv_wgrad(const void* x, const void* patches, float* dw, int dty
     return wgrad_launch(g, patches, ld, 0, 4 * nc, 16, &m, dw, (float*)workspace, workspace_bytes, dtype, (hipStream_t)stream);
 }
 
+// ---- classifier head of the ImageNet pre-training variant
+int erf_maxpool2_avgpool_fwd(const void* x, int dtype, float* feat, int N, int H, int W, int C, void* stream) {
+    if (!x || !feat || !dtype_ok(dtype) || N <= 0 || C <= 0 || H < 2 || W < 2 || ((H | W) & 1)) return ERF_EINVAL;
+    return pool_mean_fwd_launch(x, dtype, feat, N, H, W, C, (hipStream_t)stream);
+}
+
+int erf_maxpool2_avgpool_bwd(const void* x, const float* dfeat, void* dx, int dtype, int N, int H, int W, int C, void* stream) {
+    if (!x || !dfeat || !dx || !dtype_ok(dtype) || N <= 0 || C <= 0 || H < 2 || W < 2 || ((H | W) & 1)) return ERF_EINVAL;
+    return pool_mean_bwd_launch(x, dfeat, dx, dtype, N, H, W, C, (hipStream_t)stream);
+}
+
+int erf_linear_fwd(const float* f, const float* w, const float* b, float* y, int N, int C, int K, void* stream) {
+    if (!f || !w || !y || N <= 0 || C <= 0 || K <= 0) return ERF_EINVAL;
+    return linear_fwd_launch(f, w, b, y, N, C, K, (hipStream_t)stream);
+}
+
+int erf_linear_bwd(const float* f, const float* w, const float* dy, float* df, float* dw, float* db, int N, int C, int K,
+                   void* stream) {
+    if (!f || !w || !dy || !df || !dw || !db || N <= 0 || C <= 0 || K <= 0) return ERF_EINVAL;
+    return linear_bwd_launch(f, w, dy, df, dw, db, N, C, K, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -53,3 +53,10 @@ int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_p
 // Factorized-convolution weight gradient on lattice tiles (bf16).  ERF_EUNSUPPORTED: use wgrad_launch.
 int wgrad1d_launch(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis, int dilation,
                    const PackParams& map, float* workspace, size_t workspace_bytes, hipStream_t stream);
+
+// ---- classifier head of the ImageNet variant (head.hip)
+int pool_mean_fwd_launch(const void* x, int dtype, float* feat, int N, int H, int W, int C, hipStream_t stream);
+int pool_mean_bwd_launch(const void* x, const float* dfeat, void* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);
+int linear_fwd_launch(const float* f, const float* w, const float* b, float* y, int N, int C, int K, hipStream_t stream);
+int linear_bwd_launch(const float* f, const float* w, const float* dy, float* df, float* dw, float* db, int N, int C, int K,
+                      hipStream_t stream);

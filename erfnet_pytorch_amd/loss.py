@@ -28,6 +28,9 @@ class _WeightedCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, weight, group):
         ops.require_gpu(logits, "CrossEntropyLoss2d")
+        ctx.flat = logits.dim() == 2                 # [N, K] classifier logits (imagenet/main.py:81): one "pixel" per image
+        if ctx.flat:
+            logits, target = logits[:, :, None, None], target[:, None, None]
         logits = logits.contiguous()
         target = target.contiguous()
         if target.dtype != torch.int64:
@@ -55,7 +58,7 @@ class _WeightedCE(torch.autograd.Function):
         wt = ctx.weight
         call("erf_weighted_ce_bwd", logits.data_ptr(), ops.dt(logits), target.data_ptr(), 0 if wt is None else wt.data_ptr(),
              n, c, h * w, coef.data_ptr(), dlogits.data_ptr(), _stream())
-        return dlogits, None, None, None
+        return (dlogits[:, :, 0, 0] if ctx.flat else dlogits), None, None, None
 
 
 def weighted_cross_entropy(logits, target, weight=None, group=None):

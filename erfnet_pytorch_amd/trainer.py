@@ -135,6 +135,65 @@ class Trainer:
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_count, 1.0, st)
 
 
+class ArenaSGD:
+    """Training step of the ImageNet pre-training recipe (imagenet/main.py:81-85 of the reference:
+    CrossEntropyLoss + SGD(lr, momentum 0.9, weight_decay 1e-4)) for any model built from this package's blocks.
+
+    Same arrangement as Trainer: parameters, gradients and momentum buffers live in flat fp32 arenas; the
+    convolution blocks' backward kernels write into the gradient arena directly, every other parameter's
+    `.grad` is a view of it; with world_size > 1 the loss is the global-batch mean and the arena is summed
+    over the ranks (RCCL) in one all-reduce before one fused SGD launch."""
+
+    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, group=None, world_size=1):
+        self.model, self.lr, self.momentum, self.wd = model, lr, momentum, weight_decay
+        self.group, self.world = group, world_size
+        self.step_count = 0
+        named = list(model.named_parameters())
+        dev = named[0][1].device
+        total = sum(p.numel() for _, p in named)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buf = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets, off = {}, 0
+        for name, p in named:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + n].view_as(p)
+            self.offsets[name] = (off, n)
+            off += n
+        sunk = set()
+        for mname, mod in model.named_modules():
+            if not isinstance(mod, (E.DownsamplerBlock, E.UpsamplerBlock, E.non_bottleneck_1d)):
+                continue
+            views = {}
+            for k, prm in mod.named_parameters(recurse=True):
+                o, n = self.offsets[f"{mname}.{k}"]
+                views[k] = self.gflat[o:o + n].view_as(prm)
+                sunk.add(f"{mname}.{k}")
+            mod.__dict__["_erf_grad_sink"] = views
+        self._views = [(p, self.gflat[o:o + n].view_as(p)) for (name, p), (o, n) in
+                       ((np_, self.offsets[np_[0]]) for np_ in named) if name not in sunk]
+
+    def zero_grad(self):
+        self.gflat.zero_()
+        for p, v in self._views:
+            p.grad = v                                  # autograd accumulates in place into the arena
+
+    def step(self, images, targets):
+        self.zero_grad()
+        outputs = self.model(images)
+        loss = weighted_cross_entropy(outputs, targets, None, self.group if self.world > 1 else None)
+        loss.backward()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.gflat, group=self.group)
+        call("erf_sgd_fused_arena", self.flat.data_ptr(), self.gflat.data_ptr(), self.buf.data_ptr(), self.flat.numel(),
+             float(self.lr), float(self.momentum), float(self.wd), int(self.step_count == 0), 1.0,
+             torch.cuda.current_stream().cuda_stream)
+        self.step_count += 1
+        return loss.detach(), outputs.detach()
+
+
 # ------------------------------------------------------------------------------------------ benchmark leg
 def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     """BASELINE.json configs[2]: ERFNet(20) training, batch 6 per GPU, 3x512x1024 synthetic images,
@@ -179,4 +238,40 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
                                f"3x{args.height}x{args.width}, data parallel x{world}",
                    "global_batch": batch * world, "final_loss": float(loss)},
         "model_tflops": value * flop_img / 1e12,
+    }
+
+
+def bench_imagenet(args, world, rank, dev, barrier, max_over_ranks):
+    """BASELINE.json configs[3]: erfnet_imagenet.ERFNet(1000) training, batch 32 per GPU, 3x224x224 synthetic images,
+    CrossEntropyLoss, SGD(0.1, 0.9, 1e-4), data parallel over `world` ranks."""
+    import torch.distributed as dist
+    from . import erfnet_imagenet as EI, synthetic as S
+    batch = args.batch or 32
+    model = EI.ERFNet(1000)
+    S.load_synthetic(model)
+    model = model.to(dev).train()
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    tr = ArenaSGD(model, 0.1, 0.9, 1e-4, group=dist.group.WORLD if world > 1 else None, world_size=world)
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    x = torch.randn(batch, 3, 224, 224, device=dev, generator=gen)
+    t = torch.randint(0, 1000, (batch,), device=dev, generator=gen)
+    for _ in range(max(args.warmup, 1)):
+        loss, _ = tr.step(x, t)
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.step(x, t)
+    torch.cuda.synchronize()
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    value = world * batch * args.steps / elapsed
+    return {
+        "metric": "img/s erfnet_imagenet.ERFNet(1000) 224x224 training (config 4)",
+        "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"erfnet_imagenet.ERFNet(1000) training step (fwd + CE + bwd + RCCL all-reduce + SGD), batch {batch}/GPU, "
+                               f"3x224x224, data parallel x{world}", "global_batch": batch * world, "final_loss": float(loss)},
+        "model_tflops": value * 12.35e9 / 1e12,
     }

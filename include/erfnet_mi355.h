@@ -223,6 +223,18 @@ int erf_upsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, int
 int erf_output_conv_wgrad(const void* x, const void* patches, float* dw, int dtype, int N, int Hin, int Win, int nc,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- classifier head of the ImageNet pre-training variant, train/erfnet_imagenet.py:97-120 ----
+ * Features.forward after the encoder: MaxPool2d(2, stride 2) -> AvgPool2d(14, 1, 0) on the 28x28 map
+ * -> view(N, C); Classifier: Linear(C, K).  x: NHWC [N,H,W,C] (H = W = 28 in the reference; any even
+ * H, W averages all pooled positions), feat / dfeat: fp32 [N,C]; dx: gradient at x (every element
+ * written; the first maximum of a window takes the gradient, as torch's max-pool backward).
+ * Linear: f [N,C], w [K,C], b [K] (may be NULL), y / dy [N,K], all fp32; bwd overwrites df, dw, db. */
+int erf_maxpool2_avgpool_fwd(const void* x, int dtype, float* feat, int N, int H, int W, int C, void* stream);
+int erf_maxpool2_avgpool_bwd(const void* x, const float* dfeat, void* dx, int dtype, int N, int H, int W, int C, void* stream);
+int erf_linear_fwd(const float* f, const float* w, const float* b, float* y, int N, int C, int K, void* stream);
+int erf_linear_bwd(const float* f, const float* w, const float* dy, float* df, float* dw, float* db, int N, int C, int K,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
