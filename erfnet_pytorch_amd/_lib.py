@@ -49,6 +49,7 @@ SIGNATURES = {
     "erf_maxpool2_avgpool_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "erf_linear_fwd": (I, [P, P, P, P, I, I, I, P]),
     "erf_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "erf_conv1d_pack_many": (I, [P, I, I, I, P]),
     "erf_conv1d_pair": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "erf_downsampler_packed_bytes": (c_size_t, [I, I, I]),
     "erf_downsampler_pack": (I, [P, P, I, I, I, P]),

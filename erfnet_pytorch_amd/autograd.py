@@ -168,12 +168,12 @@ class _NB1dFn(torch.autograd.Function):
         code = ops.dt(xh)
         d = mod.dilated
         training = mod.training
-        a1 = ops.conv1d(xh, ops.pack_conv1d(w1, code), None, _f32(b1), None, AXIS_H, 1, True)
-        z2 = ops.conv1d(a1, ops.pack_conv1d(w2, code), None, _f32(b2), None, AXIS_W, 1, False)
+        a1 = ops.conv1d(xh, ops.packed_conv1d(mod, "conv3x1_1", w1, code), None, _f32(b1), None, AXIS_H, 1, True)
+        z2 = ops.conv1d(a1, ops.packed_conv1d(mod, "conv1x3_1", w2, code), None, _f32(b2), None, AXIS_W, 1, False)
         mean1, invstd1, s1, t1 = bn_forward_stats(z2, mod.bn1, training)
         a2 = bn_apply(z2, mean1, s1, t1)
-        a3 = ops.conv1d(a2, ops.pack_conv1d(w3, code), None, _f32(b3), None, AXIS_H, d, True)
-        z4 = ops.conv1d(a3, ops.pack_conv1d(w4, code), None, _f32(b4), None, AXIS_W, d, False)
+        a3 = ops.conv1d(a2, ops.packed_conv1d(mod, "conv3x1_2", w3, code), None, _f32(b3), None, AXIS_H, d, True)
+        z4 = ops.conv1d(a3, ops.packed_conv1d(mod, "conv1x3_2", w4, code), None, _f32(b4), None, AXIS_W, d, False)
         mean2, invstd2, s2, t2 = bn_forward_stats(z4, mod.bn2, training)
         mask = None
         if training and mod.dropout.p != 0:
@@ -194,18 +194,18 @@ class _NB1dFn(torch.autograd.Function):
                                             dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
         db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)))
         dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
-        dz3 = conv1d_dgrad(dz4, ops.pack_conv1d(w4, code, 1), a3, None, AXIS_W, d)
+        dz3 = conv1d_dgrad(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d)
         db3 = channel_sum(dz3, o("conv3x1_2.bias", (c,)))
         dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape))
-        da2 = conv1d_dgrad(dz3, ops.pack_conv1d(w3, code, 1), None, None, AXIS_H, d)
+        da2 = conv1d_dgrad(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), None, None, AXIS_H, d)
         dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
                                         dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
         db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)))
         dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
-        dz1 = conv1d_dgrad(dz2, ops.pack_conv1d(w2, code, 1), a1, None, AXIS_W, 1)
+        dz1 = conv1d_dgrad(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1)
         db1 = channel_sum(dz1, o("conv3x1_1.bias", (c,)))
         dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape))
-        dx = conv1d_dgrad(dz1, ops.pack_conv1d(w1, code, 1), None, g_res, AXIS_H, 1)
+        dx = conv1d_dgrad(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), None, g_res, AXIS_H, 1)
         return (ops.to_nchw_view(dx), None) + sk.ret(dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)
 
 

@@ -32,6 +32,11 @@ int erf_conv1d_pack(const float* w, void* packed, int dtype, int C, int mode, vo
     return pack_launch(p, dtype, (hipStream_t)stream);
 }
 
+int erf_conv1d_pack_many(const long long* table, int count, int max_c, int dtype, void* stream) {
+    if (!table || count <= 0 || !dtype_ok(dtype) || (max_c != 16 && max_c != 64 && max_c != 128)) return ERF_EINVAL;
+    return pack1d_many_launch(table, count, max_c, dtype, (hipStream_t)stream);
+}
+
 int erf_conv1d_factorized(const void* x, void* y, const void* packed, const float* scale, const float* shift,
                           const void* residual, int dtype, int N, int H, int W, int C, int axis, int dilation, int relu,
                           void* stream) {

@@ -16,3 +16,4 @@ struct PackParams {
 };
 
 int pack_launch(const PackParams& p, int dtype, hipStream_t stream);
+int pack1d_many_launch(const long long* table, int count, int max_c, int dtype, hipStream_t stream);

@@ -38,6 +38,45 @@ __global__ void pack_kernel(const PackParams p) {
     *((i32x4*)p.dst + idx) = *(const i32x4*)out;
 }
 
+// Many factorized-convolution weights in one launch.  table[4*e ..]: {fp32 weight pointer, packed pointer, C, mode}
+// (mode 0 forward, 1 data-gradient), blockIdx.y = entry; same fragment layout as pack_kernel with ntaps = 3.
+template <typename T>
+__global__ void pack1d_many_kernel(const long long* __restrict__ table) {
+    constexpr int EPC = Elem<T>::EPC;
+    const long long* ent = table + 4 * (long long)blockIdx.y;
+    const float* src = (const float*)ent[0];
+    i32x4* dst = (i32x4*)ent[1];
+    const int C = (int)ent[2], mode = (int)ent[3];
+    const int CH = C / EPC, ksteps = (3 * CH + 3) / 4;
+    const int total = (C / 16) * ksteps * 64;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, rest = idx >> 6;
+    const int ks = rest % ksteps, ct = rest / ksteps;
+    const int co = ct * 16 + (lane & 15);
+    const int g = ks * 4 + (lane >> 4);
+    const int tap = g / CH, chunk = g % CH;
+    const long long s_co = mode == 0 ? 3LL * C : 3, s_ci = mode == 0 ? 3 : 3LL * C;
+    const int toff = mode == 0 ? tap : 2 - tap;
+    T out[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        float v = 0.f;
+        if (tap < 3) v = src[co * s_co + (chunk * EPC + e) * s_ci + toff];
+        out[e] = Elem<T>::from_f32(v);
+    }
+    dst[idx] = *(const i32x4*)out;
+}
+
+int pack1d_many_launch(const long long* table, int count, int max_c, int dtype, hipStream_t stream) {
+    const int epc = dtype == 1 ? 8 : 4;
+    const int total = (max_c / 16) * ((3 * (max_c / epc) + 3) / 4) * 64;
+    const dim3 grid((total + 255) / 256, count);
+    if (dtype == 1) hipLaunchKernelGGL(pack1d_many_kernel<bf16raw>, grid, dim3(256), 0, stream, table);
+    else hipLaunchKernelGGL(pack1d_many_kernel<float>, grid, dim3(256), 0, stream, table);
+    return erf_check_launch();
+}
+
 int pack_launch(const PackParams& p, int dtype, hipStream_t stream) {
     const long long total = (long long)p.ct * p.ksteps * 64;
     if (total <= 0) return ERF_EINVAL;

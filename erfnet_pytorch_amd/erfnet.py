@@ -50,7 +50,7 @@ class _Block(nn.Module):
     """Shared plumbing: per-(dtype, parameter-version) cache of packed weights and folded affines."""
 
     def _cached(self, code: int):
-        key = (code, self.training) + tuple(v for m in self.modules() for v in _versions(m))
+        key = (code, self.training, ops.PARAM_EPOCH[0]) + tuple(v for m in self.modules() for v in _versions(m))
         cache = self.__dict__.get("_erf_cache")
         if cache is None or cache[0] != key:
             cache = (key, self._prepare(code))
@@ -175,7 +175,7 @@ class Encoder(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None
 
     def _head(self, code):
-        key = (code,) + _versions(self.output_conv)
+        key = (code, ops.PARAM_EPOCH[0]) + _versions(self.output_conv)
         cache = self.__dict__.get("_erf_head")
         if cache is None or cache[0] != key:
             cache = (key, ops.pack_pointwise(self.output_conv.weight.flatten(1), code),
@@ -215,7 +215,7 @@ class Decoder(nn.Module):
         self.output_conv = nn.ConvTranspose2d(16, num_classes, 2, stride=2, padding=0, output_padding=0, bias=True)
 
     def _head(self, code):
-        key = (code,) + _versions(self.output_conv)
+        key = (code, ops.PARAM_EPOCH[0]) + _versions(self.output_conv)
         cache = self.__dict__.get("_erf_head")
         if cache is None or cache[0] != key:
             cache = (key, ops.pack_output_conv(self.output_conv.weight, code),

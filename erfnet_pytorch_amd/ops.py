@@ -66,6 +66,64 @@ def nhwc_to_nchw_contiguous(y: torch.Tensor, dtype: torch.dtype | None = None) -
 
 
 # --------------------------------------------------------------------------- weight packing
+# Optimisers that update parameters through raw pointers (the fused arena kernels) do not bump torch's
+# per-tensor version counters; they bump this epoch instead, and every weight-derived cache keys on it.
+PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    PARAM_EPOCH[0] += 1
+
+
+class PackedBank:
+    """Persistent packed buffers (forward and data-gradient form) of all factorized convolutions of a model,
+    refreshed by ONE launch (erf_conv1d_pack_many).  `refresh()` must run after every parameter update and
+    before the next forward; blocks look their weights up through `lookup` and fall back to packing on the
+    fly when the bank is stale or was built for another dtype."""
+
+    def __init__(self, model, code: int):
+        from . import erfnet as E
+        self.code, self.epoch = code, -1
+        self.max_c = 16
+        self._entries = []                                   # (weight parameter, packed buffer, C, mode)
+        dev = next(model.parameters()).device
+        for mod in model.modules():
+            if not isinstance(mod, E.non_bottleneck_1d):
+                continue
+            bank = {}
+            for name in ("conv3x1_1", "conv1x3_1", "conv3x1_2", "conv1x3_2"):
+                w = getattr(mod, name).weight
+                c = w.shape[0]
+                self.max_c = max(self.max_c, c)
+                for mode in (0, 1):
+                    buf = _packed(query("erf_conv1d_packed_bytes", code, c), dev)
+                    bank[(name, mode)] = buf
+                    self._entries.append((w, buf, c, mode))
+            mod.__dict__["_erf_packed_bank"] = (self, bank)
+        self.count = len(self._entries)
+        self._sig, self.table = None, None
+
+    def refresh(self):
+        sig = tuple(w.data_ptr() for (w, _b, _c, _m) in self._entries)
+        if sig != self._sig:                                 # parameters moved (first use, .to(), arena re-binding)
+            rows = [[w.data_ptr(), b.data_ptr(), c, m] for (w, b, c, m) in self._entries]
+            self.table = torch.tensor(rows, dtype=torch.int64).to(self._entries[0][1].device) if rows else None
+            self._sig = sig
+        if self.count:
+            call("erf_conv1d_pack_many", self.table.data_ptr(), self.count, self.max_c, self.code, _stream())
+        self.epoch = PARAM_EPOCH[0]
+
+
+def packed_conv1d(mod, name: str, w: torch.Tensor, code: int, mode: int = 0) -> torch.Tensor:
+    """Packed weights of `mod.<name>`: from the model's PackedBank when it is current, else packed now."""
+    ent = mod.__dict__.get("_erf_packed_bank")
+    if ent is not None:
+        bank, bufs = ent
+        if bank.code == code and bank.epoch == PARAM_EPOCH[0] and getattr(mod, name).weight.data_ptr() == w.data_ptr():
+            return bufs[(name, mode)]
+    return pack_conv1d(w, code, mode)
+
+
 def _packed(nbytes: int, device) -> torch.Tensor:
     if nbytes <= 0:
         raise _lib.ErfError("unsupported layer shape for packing")

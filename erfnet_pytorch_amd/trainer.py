@@ -43,6 +43,17 @@ def poly_lr(base_lr, epoch, num_epochs):
     return base_lr * math.pow(1 - ((epoch - 1) / num_epochs), 0.9)
 
 
+def _refresh_bank(bank, model, images):
+    """(Re)build the model's PackedBank for the step's compute dtype and re-pack every factorized-conv weight."""
+    from . import ops
+    cd = getattr(model, "compute_dtype", None)
+    code = ops.dt(images) if cd is None else (ops.BF16 if cd == torch.bfloat16 else ops.F32)
+    if bank is None or bank.code != code:
+        bank = ops.PackedBank(model, code)
+    bank.refresh()
+    return bank
+
+
 class Trainer:
     def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
                  group=None, world_size=1, overlap=True):
@@ -84,6 +95,7 @@ class Trainer:
                 views[k] = self.gflat[o:o + n].view_as(prm)
             mod.__dict__["_erf_grad_sink"] = views
 
+        self._bank = None                               # packed factorized-conv weights, refreshed once per step
         # all-reduce buckets (backward-completion order) and the ranges Adam may touch
         self.buckets, self.active = dp.bucket_ranges(self.offsets)
         self._pending = []
@@ -119,6 +131,7 @@ class Trainer:
         """images [N,3,H,W]; targets [N,1,H,W] or [N,H,W] int64.  Returns the (global) loss tensor."""
         if targets.dim() == 4:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
+        self._refresh_packed(images)
         outputs = self.model(images)
         loss = weighted_cross_entropy(outputs, targets, self.weight, self.group if self.world > 1 else None)
         loss.backward()
@@ -126,7 +139,12 @@ class Trainer:
         self.optimizer_step()
         return loss.detach(), outputs.detach()
 
+    def _refresh_packed(self, images):
+        self._bank = _refresh_bank(self._bank, self.model, images)
+
     def optimizer_step(self):
+        from . import ops
+        ops.bump_param_epoch()                          # parameters change below through raw pointers
         self.step_count += 1
         st = torch.cuda.current_stream().cuda_stream
         for lo, hi in self.active:
@@ -181,12 +199,15 @@ class ArenaSGD:
 
     def step(self, images, targets):
         self.zero_grad()
+        self._bank = _refresh_bank(getattr(self, "_bank", None), self.model, images)
         outputs = self.model(images)
         loss = weighted_cross_entropy(outputs, targets, None, self.group if self.world > 1 else None)
         loss.backward()
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.gflat, group=self.group)
+        from . import ops
+        ops.bump_param_epoch()
         call("erf_sgd_fused_arena", self.flat.data_ptr(), self.gflat.data_ptr(), self.buf.data_ptr(), self.flat.numel(),
              float(self.lr), float(self.momentum), float(self.wd), int(self.step_count == 0), 1.0,
              torch.cuda.current_stream().cuda_stream)

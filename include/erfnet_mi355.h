@@ -50,6 +50,10 @@ int erf_version(void);
  * which makes the same kernel compute dL/dx from dL/dy. */
 size_t erf_conv1d_packed_bytes(int dtype, int C);
 int erf_conv1d_pack(const float* w, void* packed, int dtype, int C, int mode, void* stream);
+/* erf_conv1d_pack for `count` weights in one launch (a training step re-packs all 68 factorized convolutions,
+ * forward and data-gradient form, after every optimiser update).  table: device array of count x 4 int64
+ * {fp32 weight address, packed buffer address, C, mode}; max_c = largest C in the table (16, 64 or 128). */
+int erf_conv1d_pack_many(const long long* table, int count, int max_c, int dtype, void* stream);
 int erf_conv1d_factorized(const void* x, void* y, const void* packed, const float* scale, const float* shift,
                           const void* residual, int dtype, int N, int H, int W, int C, int axis, int dilation,
                           int relu, void* stream);

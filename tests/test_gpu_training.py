@@ -383,3 +383,33 @@ def test_trainer_step_matches_golden_and_autograd():
         m0, v0 = torch.zeros_like(p0), torch.zeros_like(p0)
         O.adam_step([p0], [gk], [m0], [v0], 1, lr=tr.lr)
         assert rel_err(params[k].detach().cpu(), p0) <= 1e-6, k
+
+
+def test_caches_follow_raw_pointer_parameter_updates():
+    """The fused optimiser writes parameters through raw pointers (no torch version bump): eval-mode caches of
+    packed weights / folded BatchNorm and the trainer's packed-weight bank must still see the new values."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.trainer import Trainer
+    model = E.ERFNet(20)
+    model.load_state_dict(O.synthetic_state(O.erfnet_template(20)))
+    model = model.to(DEV)
+    x = S.synthetic_images(2, 64, 128, seed=91).to(DEV)
+    t = S.synthetic_labels(2, 64, 128, 20, seed=91).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        y0 = model(x).clone()                      # fills the eval caches
+    model.train()
+    tr = Trainer(model, O.CITYSCAPES_WEIGHTS, lr=5e-3)
+    for _ in range(2):
+        tr.zero_grad()
+        tr.step(x, t)
+    model.eval()
+    with torch.no_grad():
+        y1 = model(x)
+    fresh = E.ERFNet(20)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad():
+        y2 = fresh(x)
+    assert rel_err(y1.cpu(), y0.cpu()) > 1e-3      # the parameters did move
+    assert torch.equal(y1, y2)
