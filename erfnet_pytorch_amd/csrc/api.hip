@@ -180,6 +180,7 @@ int erf_output_conv_pack(const float* w, void* packed, int dtype, int nc, void* 
     p.src = w; p.dst = packed; p.cin = 16; p.cout_virtual = 4 * ncp; p.ncp = ncp; p.nc_valid = nc;
     p.s_co = 4; p.s_phase = 1; p.s_ci = 4LL * nc; p.ntaps = 1; p.toff[0] = 0;       // weight [16][nc][2][2]
     p.ct = ct_of(4 * ncp); p.ksteps = gconv_ksteps(dtype, 16, 1);
+    p.interleave4 = 1;          // tile c, row 4*phase + e  <->  class 4c + e: a lane of the MFMA result owns one phase
     return pack_launch(p, dtype, (hipStream_t)stream);
 }
 

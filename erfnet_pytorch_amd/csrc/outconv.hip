@@ -1,88 +1,82 @@
 // Decoder.output_conv: ConvTranspose2d(16, nc, 2, stride 2) with the per-pixel arg-max fused.
 //
 // Every input pixel owns its 2x2 output patch, so the layer is one small GEMM per pixel:
-// 16 input channels -> 4 * NCP "virtual channels" v = phase * NCP + class, phase = 2a + b the
-// position inside the patch, NCP = nc rounded up to a multiple of 4 (so the 4 accumulator
-// registers of a lane always belong to one phase).  With output channels on the MFMA row axis
-// a lane ends up with 4 consecutive classes of one phase of one input pixel; the arg-max over
-// the classes of a phase is finished with two cross-lane exchanges (lane ^ 16, lane ^ 32).
-// Labels come from the fp32 accumulators, so the logits need not be materialised at all.
+// 16 input channels -> 4 * nc outputs (phase = 2a + b, the position inside the patch, x class).
+// The weight rows are packed so that MFMA tile c, row 4*phase + e is class 4c + e: after the MFMAs
+// lane (q, r) holds ALL classes of phase q of input pixel r, i.e. of output pixel (2i + (q>>1), 2j + (q&1)).
+// The arg-max over the classes therefore needs no cross-lane traffic at all, and the labels come from
+// the fp32 accumulators -- the logits need not be materialised.  Byte labels of four horizontally
+// adjacent output pixels are gathered with two lane exchanges and leave as one 4-byte store.
 #include "common.cuh"
 #include "misc.cuh"
+#include "conv1d_tile.cuh"
 
 template <typename T, int CT, int PT>
 __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, const i32x4* __restrict__ w,
                                                       const float* __restrict__ bias, void* __restrict__ logits,
                                                       int logits_mode, void* __restrict__ labels, int label_bytes, int N,
-                                                      int Hin, int Win, int nc, int ncp) {
+                                                      int Hin, int Win, int nc, FastDiv fW, FastDiv fH) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int CH = 16 / EPC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, r16 = lane & 15;
-    const long long P = (long long)N * Hin * Win;
-    const long long tile0 = ((long long)blockIdx.x * 4 + wave) * (16 * PT);
+    const unsigned P = (unsigned)N * Hin * Win;
+    const unsigned tile0 = (blockIdx.x * 4 + wave) * (16 * PT);
     const int Hout = 2 * Hin, Wout = 2 * Win;
 
     i32x4 a[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) a[c] = w[c * 64 + lane];
+    float bs[CT][4];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[c][e] = 4 * c + e < nc ? bias[4 * c + e] : 0.f;
 
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-        const long long pix = tile0 + t * 16 + r16;
+        const unsigned pix = tile0 + t * 16 + r16;
         const bool pv = pix < P;
         i32x4 b = {0, 0, 0, 0};
-        if (pv && q < CH) b = *(const i32x4*)(x + pix * 16 + q * EPC);
+        if (pv && q < CH) b = *(const i32x4*)(x + (long long)pix * 16 + q * EPC);
         f32x4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = mma_step<T>(a[c], b, f32x4{0.f, 0.f, 0.f, 0.f});
 
-        const long long pp = pv ? pix : 0;
-        const int j = (int)(pp % Win);
-        const long long rest = pp / Win;
-        const int i = (int)(rest % Hin);
-        const int n = (int)(rest / Hin);
+        const unsigned pp = pv ? pix : 0;
+        const unsigned rest = fast_div(pp, fW);
+        const int j = (int)(pp - rest * fW.div);
+        const unsigned n = fast_div(rest, fH);
+        const int i = (int)(rest - n * fH.div);
+        const int oh = 2 * i + (q >> 1), ow = 2 * j + (q & 1);
 
-        float bv[4];
-        int bi[4];
+        float bv = -INFINITY;
+        int bi = 0;
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) { bv[ph] = -INFINITY; bi[ph] = 0x7FFFFFFF; }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int v0 = c * 16 + q * 4;
-            const int ph = v0 / ncp, cls0 = v0 % ncp;
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int cls = cls0 + e;
-                const bool ok = ph < 4 && cls < nc;
-                const float val = acc[c][e] + (ok ? bias[cls] : 0.f);
-                if (ok && pv && logits_mode) {
-                    const long long o = (((long long)n * nc + cls) * Hout + 2 * i + (ph >> 1)) * Wout + 2 * j + (ph & 1);
-                    if (logits_mode == 2) ((float*)logits)[o] = val;
-                    else Elem<T>::st((T*)logits + o, val);
+                const int cls = 4 * c + e;
+                if (cls < nc) {                                  // wave-uniform
+                    const float val = acc[c][e] + bs[c][e];
+                    if (logits_mode && pv) {
+                        const long long o = (((long long)n * nc + cls) * Hout + oh) * Wout + ow;
+                        if (logits_mode == 2) ((float*)logits)[o] = val;
+                        else Elem<T>::st((T*)logits + o, val);
+                    }
+                    if (val > bv) { bv = val; bi = cls; }        // first maximum wins, as torch.max(1)
                 }
-#pragma unroll
-                for (int pq = 0; pq < 4; ++pq)
-                    if (ok && ph == pq && val > bv[pq]) { bv[pq] = val; bi[pq] = cls; }
             }
-        }
         if (labels) {
-#pragma unroll
-            for (int pq = 0; pq < 4; ++pq) {
-#pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    const float ov = __shfl_xor(bv[pq], o, 64);
-                    const int oi = __shfl_xor(bi[pq], o, 64);
-                    if (ov > bv[pq] || (ov == bv[pq] && oi < bi[pq])) { bv[pq] = ov; bi[pq] = oi; }
-                }
-            }
-            int mine = bi[0];
-#pragma unroll
-            for (int pq = 1; pq < 4; ++pq) mine = (q == pq) ? bi[pq] : mine;
-            if (pv) {
-                const long long o = ((long long)n * Hout + 2 * i + (q >> 1)) * Wout + 2 * j + (q & 1);
-                if (label_bytes == 1) ((unsigned char*)labels)[o] = (unsigned char)mine;
-                else ((long long*)labels)[o] = (long long)mine;
+            const long long o = ((long long)n * Hout + oh) * Wout + ow;
+            if (label_bytes == 1) {
+                // bytes of (b = 0, b = 1) x (j, j + 1): j even and Win even keep the four in one row and one tile
+                const int right = __shfl_xor(bi, 16, 64);
+                const int pair = bi | (right << 8);
+                const int next = __shfl_down(pair, 1, 64);
+                if (pv && !(q & 1) && !(r16 & 1)) *(unsigned int*)((unsigned char*)labels + o) = (unsigned)(pair | (next << 16));
+            } else if (pv) {
+                ((long long*)labels)[o] = (long long)bi;
             }
         }
     }
@@ -90,12 +84,12 @@ __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, c
 
 template <typename T>
 static int outconv_dispatch(int ct, dim3 grid, hipStream_t stream, const T* x, const i32x4* w, const float* bias,
-                            void* logits, int logits_mode, void* labels, int label_bytes, int N, int Hin, int Win, int nc,
-                            int ncp) {
+                            void* logits, int logits_mode, void* labels, int label_bytes, int N, int Hin, int Win, int nc) {
+    const FastDiv fW = make_fastdiv(Win), fH = make_fastdiv(Hin);
 #define OC(CTV)                                                                                                     \
     case CTV:                                                                                                       \
-        hipLaunchKernelGGL((outconv_kernel<T, CTV, 2>), grid, dim3(256), 0, stream, x, w, bias, logits, logits_mode, \
-                           labels, label_bytes, N, Hin, Win, nc, ncp);                                              \
+        hipLaunchKernelGGL((outconv_kernel<T, CTV, 4>), grid, dim3(256), 0, stream, x, w, bias, logits, logits_mode, \
+                           labels, label_bytes, N, Hin, Win, nc, fW, fH);                                           \
         break;
     switch (ct) {
         OC(1) OC(2) OC(3) OC(4) OC(5) OC(6) OC(7) OC(8)
@@ -109,15 +103,16 @@ int outconv_launch(const void* x, const void* packed, const float* bias, void* l
                    int label_bytes, int dtype, int N, int Hin, int Win, int nc, hipStream_t stream) {
     if (nc < 1 || nc > 32) return ERF_EUNSUPPORTED;
     if (labels && label_bytes != 1 && label_bytes != 8) return ERF_EINVAL;
-    const int ncp = (nc + 3) & ~3;
-    const int ct = (4 * ncp + 15) / 16;
+    if (Win & 1) return ERF_EUNSUPPORTED;                       // the 4-byte label stores pair columns j, j + 1
+    const int ct = (nc + 3) / 4;
     const long long P = (long long)N * Hin * Win;
-    const long long gx = (P + 4 * 16 * 2 - 1) / (4 * 16 * 2);
-    if (gx <= 0 || gx > 0x7FFFFFFFLL) return ERF_EINVAL;
+    if (P >= (1LL << 31)) return ERF_EUNSUPPORTED;
+    const long long gx = (P + 4 * 16 * 4 - 1) / (4 * 16 * 4);
+    if (gx <= 0) return ERF_EINVAL;
     const int mode = logits ? (logits_f32 ? 2 : 1) : 0;
     if (dtype == 1)
         return outconv_dispatch<bf16raw>(ct, dim3((unsigned)gx), stream, (const bf16raw*)x, (const i32x4*)packed, bias,
-                                         logits, mode, labels, label_bytes, N, Hin, Win, nc, ncp);
+                                         logits, mode, labels, label_bytes, N, Hin, Win, nc);
     return outconv_dispatch<float>(ct, dim3((unsigned)gx), stream, (const float*)x, (const i32x4*)packed, bias, logits, mode,
-                                   labels, label_bytes, N, Hin, Win, nc, ncp);
+                                   labels, label_bytes, N, Hin, Win, nc);
 }

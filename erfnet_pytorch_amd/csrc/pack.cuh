@@ -13,6 +13,7 @@ struct PackParams {
     int ntaps;
     int toff[9];            // element offset of each tap in src
     int ct, ksteps;
+    int interleave4;        // rows ordered [class group of 4][phase 0..3][class in group] (16 per tile) instead of phase-major
 };
 
 int pack_launch(const PackParams& p, int dtype, hipStream_t stream);

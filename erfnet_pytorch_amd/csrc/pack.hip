@@ -22,7 +22,8 @@ __global__ void pack_kernel(const PackParams p) {
     const int co = ct * 16 + (lane & 15);
     const int g = ks * 4 + (lane >> 4);
     const int tap = g / CH, chunk = g % CH;
-    const int phase = co / p.ncp, cls = co % p.ncp;
+    int phase = co / p.ncp, cls = co % p.ncp;
+    if (p.interleave4) { phase = (co & 15) >> 2; cls = (co >> 4) * 4 + (co & 3); }
     const bool ok = tap < p.ntaps && cls < p.nc_valid && co < p.cout_virtual;
     T out[EPC];
 #pragma unroll
