@@ -57,7 +57,7 @@ struct PairGeo {
 };
 
 template <int C, int R, int TC>
-__device__ __forceinline__ PairGeo pair_geo(const PairParams& p, int tile) {
+__device__ __forceinline__ PairGeo pair_geo(const PairParams& p, int tile, int tile_end) {
     constexpr int PIXB = C * 2;
     PairGeo g;
     uint32_t t = (uint32_t)tile;
@@ -78,7 +78,7 @@ __device__ __forceinline__ PairGeo pair_geo(const PairParams& p, int tile) {
     g.in_soff = g.out_soff;                                       // + pad - one lattice row (pad == d*W*PIXB)
     g.ulo = hh0 < 0 ? 1 : 0;
     int uhi = nh - hh0;
-    uhi = tile < p.ntiles ? (uhi < R + 2 ? uhi : R + 2) : 0;
+    uhi = tile < tile_end ? (uhi < R + 2 ? uhi : R + 2) : 0;
     g.uhi = uhi > g.ulo ? uhi : g.ulo;                            // empty range when the tile lies below the image
     const int rem = nw - c0;
     g.jhi = rem < TC ? rem : TC;
@@ -301,17 +301,25 @@ void conv1d_pair_kernel(const PairParams p) {
     for (int o = tid * 16; o < MIDB; o += NT * 16) *(i32x4*)(smem + MID + o) = i32x4{0, 0, 0, 0};
 
     const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();      // max(v, floor_v): ReLU or identity without a select
-    const int G = gridDim.x;
-    int tile = blockIdx.x;
-    PairGeo g = pair_geo<C, R, TC>(p, tile);
-    PairGeo g1 = pair_geo<C, R, TC>(p, tile + G);
+    // Workgroups are dealt to the 8 XCDs round-robin.  Give every XCD one contiguous eighth of the tile
+    // sequence, so that tiles sharing halo rows / columns run on the same XCD at about the same time and
+    // the second fetch of a halo pixel is an L2 hit instead of another trip to HBM.
+    int tile = blockIdx.x, tile_end = p.ntiles, G = gridDim.x;
+    if ((G & 7) == 0) {
+        const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        tile = xcd * per + (blockIdx.x >> 3);
+        tile_end = (xcd + 1) * per < p.ntiles ? (xcd + 1) * per : p.ntiles;
+        G >>= 3;
+    }
+    PairGeo g = pair_geo<C, R, TC>(p, tile, tile_end);
+    PairGeo g1 = pair_geo<C, R, TC>(p, tile + G, tile_end);
     pair_dma<KI, NW>(rs_x, smem, in_rel, in_uj, g, wave);
     pair_dma<KI, NW>(rs_x, smem + BUFB, in_rel, in_uj, g1, wave);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");
     ERF_LDS_BARRIER();
 
     int cur = 0;
-    for (; tile < p.ntiles; tile += G, cur ^= 1) {
+    for (; tile < tile_end; tile += G, cur ^= 1) {
         const int boff = cur * BUFB;
 
         // ---------------- GEMM 1: 3x1 over the input tile
@@ -397,7 +405,7 @@ void conv1d_pair_kernel(const PairParams p) {
 
         const uint32_t out_soff = g.out_soff;
         g = g1;
-        g1 = pair_geo<C, R, TC>(p, tile + 2 * G);
+        g1 = pair_geo<C, R, TC>(p, tile + 2 * G, tile_end);
         pair_dma<KI, NW>(rs_x, smem + boff, in_rel, in_uj, g1, wave);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");      // this wave's share of tile k+1 has landed
 #pragma unroll
