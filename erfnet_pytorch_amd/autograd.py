@@ -59,6 +59,49 @@ def bn_forward_stats(z, bn, training):
     return bn.running_mean.float().contiguous(), invstd.contiguous(), scale.contiguous(), beta
 
 
+def conv1d_bn_stats(x, packed, bias, axis, dilation, bn, training):
+    """z = conv1d(x) + bias followed by bn_forward_stats(z): with batch statistics the sums come out of the
+    convolution's epilogue (erf_conv1d_factorized_bn) instead of a second pass over z."""
+    n, h, w, c = x.shape
+    if training:
+        dev = x.device
+        z = torch.empty_like(x)
+        gamma, beta = _f32(bn.weight), _f32(bn.bias)
+        mean, invstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        scale, shift = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        rc = query("erf_conv1d_factorized_bn", x.data_ptr(), z.data_ptr(), packed.data_ptr(), bias.data_ptr(), ops.dt(x), n, h, w, c,
+                   axis, dilation, gamma.data_ptr(), beta.data_ptr(), _p(bn.running_mean if track else None),
+                   _p(bn.running_var if track else None), momentum, bn.eps, mean.data_ptr(), invstd.data_ptr(),
+                   scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream())
+        if rc == 0:
+            if track:
+                bn.num_batches_tracked += 1
+            return z, mean, invstd, scale, beta
+        if rc != -2:
+            raise RuntimeError(f"erf_conv1d_factorized_bn failed with status {rc}")
+    z = ops.conv1d(x, packed, None, bias, None, axis, dilation, False)
+    return (z,) + tuple(bn_forward_stats(z, bn, training))
+
+
+def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=None):
+    """dx = conv1d_dgrad(...) and the bias gradient sum_p dx[p][c] of the convolution that produced dx's tensor."""
+    n, h, w, c = dy.shape
+    dx = torch.empty_like(dy)
+    db = torch.empty(c, device=dy.device) if dbias_out is None else dbias_out
+    ws = _ws(query("erf_bn_workspace_bytes", c), dy.device)
+    rc = query("erf_conv1d_dgrad_bias", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), _p(gate), _p(residual), ops.dt(dy), n, h, w,
+               c, axis, dilation, db.data_ptr(), ws.data_ptr(), _stream())
+    if rc == 0:
+        return dx, db
+    if rc != -2:
+        raise RuntimeError(f"erf_conv1d_dgrad_bias failed with status {rc}")
+    dx = conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation)
+    return dx, channel_sum(dx, db)
+
+
 def bn_apply(z, center, scale, shift, residual=None, mask=None, relu=True):
     """y = act(((z - center) * scale + shift) * mask + residual)"""
     n, h, w, c = z.shape
@@ -169,12 +212,12 @@ class _NB1dFn(torch.autograd.Function):
         d = mod.dilated
         training = mod.training
         a1 = ops.conv1d(xh, ops.packed_conv1d(mod, "conv3x1_1", w1, code), None, _f32(b1), None, AXIS_H, 1, True)
-        z2 = ops.conv1d(a1, ops.packed_conv1d(mod, "conv1x3_1", w2, code), None, _f32(b2), None, AXIS_W, 1, False)
-        mean1, invstd1, s1, t1 = bn_forward_stats(z2, mod.bn1, training)
+        z2, mean1, invstd1, s1, t1 = conv1d_bn_stats(a1, ops.packed_conv1d(mod, "conv1x3_1", w2, code), _f32(b2), AXIS_W, 1,
+                                                     mod.bn1, training)
         a2 = bn_apply(z2, mean1, s1, t1)
         a3 = ops.conv1d(a2, ops.packed_conv1d(mod, "conv3x1_2", w3, code), None, _f32(b3), None, AXIS_H, d, True)
-        z4 = ops.conv1d(a3, ops.packed_conv1d(mod, "conv1x3_2", w4, code), None, _f32(b4), None, AXIS_W, d, False)
-        mean2, invstd2, s2, t2 = bn_forward_stats(z4, mod.bn2, training)
+        z4, mean2, invstd2, s2, t2 = conv1d_bn_stats(a3, ops.packed_conv1d(mod, "conv1x3_2", w4, code), _f32(b4), AXIS_W, d,
+                                                     mod.bn2, training)
         mask = None
         if training and mod.dropout.p != 0:
             mask = dropout_mask(xh.shape[0], xh.shape[3], mod.dropout.p, xh.device, mod.__dict__.get("_erf_forced_mask"))
@@ -194,16 +237,16 @@ class _NB1dFn(torch.autograd.Function):
                                             dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
         db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)))
         dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
-        dz3 = conv1d_dgrad(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d)
-        db3 = channel_sum(dz3, o("conv3x1_2.bias", (c,)))
+        dz3, db3 = conv1d_dgrad_bias(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d,
+                                     o("conv3x1_2.bias", (c,)))
         dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape))
         da2 = conv1d_dgrad(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), None, None, AXIS_H, d)
         dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
                                         dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
         db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)))
         dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
-        dz1 = conv1d_dgrad(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1)
-        db1 = channel_sum(dz1, o("conv3x1_1.bias", (c,)))
+        dz1, db1 = conv1d_dgrad_bias(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1,
+                                     o("conv3x1_1.bias", (c,)))
         dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape))
         dx = conv1d_dgrad(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), None, g_res, AXIS_H, 1)
         return (ops.to_nchw_view(dx), None) + sk.ret(dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)

@@ -88,6 +88,36 @@ int erf_channel_sum(const void* z, int dtype, long long pixels, int C, float* su
     return channel_sum_finalize_launch((const float*)workspace, groups, C, sums, (hipStream_t)stream);
 }
 
+// z = conv1d(x) + bias with the BatchNorm batch statistics of z taken inside the convolution's epilogue
+int erf_conv1d_factorized_bn(const void* x, void* z, const void* packed, const float* bias, int dtype, int N, int H, int W, int C,
+                             int axis, int dilation, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                             float* shift, void* workspace, void* stream) {
+    if (!x || !z || !packed || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace || !dtype_ok(dtype) ||
+        N <= 0 || H <= 0 || W <= 0 || dilation < 1 || (axis != ERF_AXIS_H && axis != ERF_AXIS_W))
+        return ERF_EINVAL;
+    if (C != 16 && C != 64 && C != 128) return ERF_EUNSUPPORTED;
+    int groups = 0;
+    int rc = conv1d_buf_launch(x, z, packed, nullptr, bias, nullptr, nullptr, (double*)workspace, &groups, dtype, N, H, W, C, axis,
+                               dilation, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return bn_finalize_launch((const float*)workspace, groups, C, (long long)N * H * W, gamma, beta, running_mean, running_var,
+                              momentum, eps, mean, invstd, scale, shift, (hipStream_t)stream);
+}
+
+// dx = conv1d_dgrad(dy) * [gate > 0] + residual, and dbias[c] = sum over pixels of dx[p][c] from the same launch
+int erf_conv1d_dgrad_bias(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual, int dtype,
+                          int N, int H, int W, int C, int axis, int dilation, float* dbias, void* workspace, void* stream) {
+    if (!dy || !dx || !packed_t || !dbias || !workspace || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || dilation < 1)
+        return ERF_EINVAL;
+    if (C != 16 && C != 64 && C != 128) return ERF_EUNSUPPORTED;
+    int groups = 0;
+    int rc = conv1d_buf_launch(dy, dx, packed_t, nullptr, nullptr, residual, gate, (double*)workspace, &groups, dtype, N, H, W, C,
+                               axis, dilation, 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return channel_sum_finalize_launch((const float*)workspace, groups, C, dbias, (hipStream_t)stream);
+}
+
 int erf_dropout2d_mask(float* mask, int count, float p, unsigned long long seed, void* stream) {
     if (!mask) return ERF_EINVAL;
     return dropout_mask_launch(mask, count, p, seed, (hipStream_t)stream);

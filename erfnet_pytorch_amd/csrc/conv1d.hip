@@ -203,299 +203,6 @@ void conv1d_kernel(const Conv1dParams p) {
     }
 }
 
-// =====================================================================================
-// Second generation of the same kernel: asynchronous staging and a coalesced epilogue.
-//
-//  * the input tile goes global -> LDS by DMA (global_load_lds, 16 bytes per lane, no VGPR
-//    round trip) into one of TWO buffers: the loads of tile k+2 are issued as soon as tile k's
-//    buffer is free and complete while tiles k and k+1 are computed.  Every lane of a DMA
-//    instruction lands at (wave base + 16*lane), so the LDS layout is addressed by physical
-//    16-byte slot and the swizzle is applied to the SOURCE address instead; out-of-image slots
-//    read a zero page;
-//  * the accumulators go back through LDS (the tile's own buffer, as [pixel][C] in the output
-//    type) and leave as whole 16-byte chunks, 64 consecutive chunks per wave instruction --
-//    full-line stores instead of 8-byte pieces 256 bytes apart; the residual / gate operand is
-//    read with the same coalesced pattern.  With a residual or gate in bf16 the value is rounded
-//    to bf16 once before and once after that operand is applied.
-// =====================================================================================
-struct TileGeo {
-    long long gp0;
-    int a_first, ulo, uhi, vhi;
-};
-
-__device__ __forceinline__ TileGeo tile_geo(const Conv1dParams& p, int tile) {
-    TileGeo g;
-    int t = tile;
-    const int cb = t % p.CB; t /= p.CB;
-    const int ca = t % p.CA; t /= p.CA;
-    const int rho = t % p.d;
-    const int img = t / p.d;
-    g.a_first = rho + (ca * p.Tm - 1) * p.d;
-    const int b0 = cb * p.Tn;
-    g.gp0 = (long long)img * p.img_stride + (long long)g.a_first * (p.stride_u / p.d) + (long long)b0 * p.stride_v;
-    g.ulo = g.a_first < 0 ? 1 : 0;
-    int uhi = (p.A - g.a_first + p.d - 1) / p.d;
-    if (uhi > p.Tm + 2) uhi = p.Tm + 2;
-    g.uhi = tile < p.ntiles ? uhi : 0;                           // past the end: an all-zero tile
-    g.vhi = p.Bn - b0 < p.Tn ? p.Bn - b0 : p.Tn;
-    return g;
-}
-
-template <typename T, int C, int NW, int KI>
-__device__ __forceinline__ void dma_tile(const Conv1dParams& p, const TileGeo& g, const T* xg, char* buf, int wave, int lane) {
-    constexpr int EPC = Elem<T>::EPC;
-    constexpr int CH = C / EPC;
-    constexpr int PIXB = C * (int)sizeof(T);
-    asm volatile("" : "+v"(lane));          // recompute the slot decode per call instead of keeping KI copies live
-#pragma unroll
-    for (int k = 0; k < KI; ++k) {
-        const int id = (k * NW + wave) * 64 + lane;              // physical 16-byte slot
-        const int pix = id / CH, slot = id % CH;
-        const int chunk = swz<PIXB>(pix, slot);
-        const int v = pix & (p.Tn - 1), u = pix >> p.log2Tn;
-        const bool ok = u >= g.ulo && u < g.uhi && v < g.vhi;    // slots past the tile have u >= Tm+2 >= uhi
-        const char* src = g_zero_page + lane * 16;
-        if (ok) src = (const char*)(xg + (g.gp0 + (long long)u * p.stride_u + (long long)v * p.stride_v) * C + chunk * EPC);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(buf + (k * NW + wave) * 1024), 16, 0, 0);
-    }
-}
-
-template <typename T, int C, int WM, int WN, int M, int KI, int OCC>
-__global__ __launch_bounds__(WM * WN * 64, OCC)
-void conv1d_dma_kernel(const Conv1dParams p) {
-    constexpr int EPC = Elem<T>::EPC;
-    constexpr int CH = C / EPC;
-    constexpr int PIXB = C * (int)sizeof(T);
-    constexpr int NW = WM * WN;
-    constexpr int NT = NW * 64;
-    constexpr int CT = C / 16;
-    constexpr int CTW = CT / WN;
-    constexpr int PTW = (M / 16) / WM;
-    constexpr int KS = (3 * CH + 3) / 4;
-    constexpr int BUFB = KI * NW * 1024;
-    constexpr int NS = (M * CH) / NT;
-    constexpr int NCL = CH >= 4 ? (CH < 16 ? CH : 16) / 4 : 1;
-    constexpr int NLB = CH >= 4 ? 3 * NCL : KS;
-    constexpr int GS = (KS % 6 == 0) ? 6 : (KS % 4 == 0 ? 4 : KS);     // reads per group
-    constexpr int NG = PTW * KS / GS;
-    static_assert(CT % WN == 0 && (M / 16) % WM == 0, "tile split");
-    static_assert((M * CH) % NT == 0 && M * PIXB <= BUFB, "epilogue staging");
-    static_assert((PTW * KS) % GS == 0, "read groups");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int q = lane >> 4, r16 = lane & 15;
-
-    i32x4 wreg[CTW][KS];
-    f32x4 sc[CTW], sh[CTW];
-    {
-        const i32x4* wp = (const i32x4*)p.w;
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wreg[c][ks] = wp[((wn * CTW + c) * KS + ks) * 64 + lane];
-            const int co = (wn * CTW + c) * 16 + q * 4;
-            sc[c] = p.scale ? *(const f32x4*)(p.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
-            sh[c] = p.shift ? *(const f32x4*)(p.shift + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
-    const T* xg = (const T*)p.x;
-    T* yg = (T*)p.y;
-    const T* rg = (const T*)p.res;
-    const T* gg = (const T*)p.gate;
-    const bool post = rg != nullptr || gg != nullptr;
-    const int Tn = p.Tn, log2Tn = p.log2Tn;
-    const int G = gridDim.x;
-
-    // Pin the weights' arrival here: otherwise the wait for them is placed at their first use inside
-    // the loop, where it would also drain the DMA prefetch on every iteration.
-#pragma unroll
-    for (int c = 0; c < CTW; ++c) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) tie_reg(wreg[c][ks]);
-        asm volatile("" : "+v"(sc[c]), "+v"(sh[c]));
-    }
-
-    int tile = blockIdx.x;
-    dma_tile<T, C, NW, KI>(p, tile_geo(p, tile), xg, smem, wave, lane);
-    dma_tile<T, C, NW, KI>(p, tile_geo(p, tile + G), xg, smem + BUFB, wave, lane);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");
-    asm volatile("s_barrier" ::: "memory");
-
-    int cur = 0;
-    for (; tile < p.ntiles; tile += G, cur ^= 1) {
-        const TileGeo g = tile_geo(p, tile);
-        const int boff = cur * BUFB;
-
-        // per-lane byte offsets of the B-fragment reads (tap and chunk class folded in)
-        int lb[NLB];
-        int r16o = r16;
-        asm volatile("" : "+v"(r16o));
-        if constexpr (CH >= 4) {
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-                for (int cl = 0; cl < NCL; ++cl)
-                    lb[tap * NCL + cl] = boff + ((wm * PTW) * 16 + tap * Tn + r16o) * PIXB + swz<PIXB>(r16o, cl * 4 + q) * 16;
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int gi = ks * 4 + q;
-                const int tap = gi / CH < 2 ? gi / CH : 2;
-                lb[ks] = boff + ((wm * PTW) * 16 + tap * Tn + r16o) * PIXB + swz<PIXB>(r16o, gi % CH) * 16;
-            }
-        }
-
-        // B fragments are read with hand-placed ds_read_b128 (the compiler would otherwise make every
-        // LDS read wait for ALL outstanding DMA, i.e. for the prefetch of the next tiles): groups of GS
-        // reads, group g+1 in flight while group g feeds the MFMAs.  LDS reads return in order, so
-        // "at most GS outstanding" means group g has arrived.
-        f32x4 acc[PTW][CTW];
-#pragma unroll
-        for (int pt = 0; pt < PTW; ++pt)
-#pragma unroll
-            for (int c = 0; c < CTW; ++c) acc[pt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (sizeof(T) == 2) {
-            i32x4 bb[2][GS];
-            auto issue = [&](auto gi, i32x4* dst) {
-                static_for<0, GS>([&](auto e) {
-                    constexpr int r = decltype(gi)::value * GS + decltype(e)::value;
-                    constexpr int pt = r / KS, ks = r % KS;
-                    constexpr int tap = (ks * 4) / CH;
-                    constexpr int li = CH >= 4 ? tap * NCL + (ks % NCL) : ks;
-                    constexpr int imm = pt * 16 * PIXB + (CH > 16 ? (((ks * 4) % CH) & ~15) * 16 : 0);
-                    static_assert(imm < 65536, "ds offset field");
-                    dst[decltype(e)::value] = lds_read_b128<imm>(lb[li]);
-                });
-            };
-            issue(std::integral_constant<int, 0>{}, bb[0]);
-            static_for<0, NG>([&](auto gi) {
-                constexpr int g = decltype(gi)::value;
-                i32x4* cb = bb[g & 1];
-                if constexpr (g + 1 < NG) {
-                    issue(std::integral_constant<int, g + 1>{}, bb[(g + 1) & 1]);
-                    wait_lgkm<GS>();
-                } else {
-                    wait_lgkm<0>();
-                }
-                static_for<0, GS>([&](auto e) { tie_reg(cb[decltype(e)::value]); });
-                static_for<0, GS>([&](auto e) {
-                    constexpr int r = g * GS + decltype(e)::value;
-                    constexpr int pt = r / KS, ks = r % KS;
-                    i32x4 b = cb[decltype(e)::value];
-                    if constexpr ((3 * CH) % 4 != 0) {
-                        if (ks * 4 + q >= 3 * CH) b = i32x4{0, 0, 0, 0};
-                    }
-    #pragma unroll
-                    for (int c = 0; c < CTW; ++c) acc[pt][c] = mma_step<T>(wreg[c][ks], b, acc[pt][c]);
-                });
-            });
-        } else {        // fp32 is MFMA-bound (4 instructions per step): compiler-scheduled reads are enough
-#pragma unroll
-            for (int pt = 0; pt < PTW; ++pt) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    int off;
-                    if constexpr (CH >= 4) {
-                        const int tap = (ks * 4) / CH;
-                        const int hi = CH > 16 ? (((ks * 4) % CH) & ~15) * 16 : 0;
-                        off = lb[tap * NCL + (ks % NCL)] + pt * 16 * PIXB + hi;
-                    } else {
-                        off = lb[ks] + pt * 16 * PIXB;
-                    }
-                    i32x4 b = *(const i32x4*)(smem + off);
-                    if constexpr ((3 * CH) % 4 != 0) {
-                        if (ks * 4 + q >= 3 * CH) b = i32x4{0, 0, 0, 0};
-                    }
-#pragma unroll
-                    for (int c = 0; c < CTW; ++c) acc[pt][c] = mma_step<T>(wreg[c][ks], b, acc[pt][c]);
-                }
-            }
-        }
-        ERF_LDS_BARRIER();                 // every wave is done reading the input tile
-
-        // ---- accumulators -> LDS as [pixel][C] in the output type
-#pragma unroll
-        for (int pt = 0; pt < PTW; ++pt) {
-            const int m = (wm * PTW + pt) * 16 + r16;
-#pragma unroll
-            for (int c = 0; c < CTW; ++c) {
-                f32x4 v = acc[pt][c];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = v[e] * sc[c][e] + sh[c][e];
-                    if (!post && p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-                if constexpr (sizeof(T) == 2) {
-                    const int chunk = (wn * CTW + c) * 2 + (q >> 1);
-                    i32x2 r;
-                    r[0] = (int)((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16));
-                    r[1] = (int)((uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
-                    *(i32x2*)(smem + boff + m * PIXB + swz<PIXB>(m, chunk) * 16 + (q & 1) * 8) = r;
-                } else {
-                    const int chunk = (wn * CTW + c) * 4 + q;
-                    *(f32x4*)(smem + boff + m * PIXB + swz<PIXB>(m, chunk) * 16) = v;
-                }
-            }
-        }
-        ERF_LDS_BARRIER();
-
-        // ---- coalesced read-back (+ gate, residual, ReLU)
-        i32x4 outv[NS];
-        long long oaddr[NS];
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));    // same: nothing of this decode stays live across tiles
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int cid = tid_o + s * NT;
-            const int m = cid / CH, chunk = cid % CH;
-            const int i = m >> log2Tn, j = m & (Tn - 1);
-            const bool ok = (g.a_first + (i + 1) * p.d < p.A) && (j < g.vhi);
-            oaddr[s] = ok ? (g.gp0 + (long long)(i + 1) * p.stride_u + (long long)j * p.stride_v) * C + chunk * EPC : -1;
-            outv[s] = *(const i32x4*)(smem + boff + m * PIXB + swz<PIXB>(m, chunk) * 16);
-        }
-        if (post) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (oaddr[s] < 0) continue;
-                float f[ChunkOps<T>::N];
-                ChunkOps<T>::unpack(outv[s], f);
-                if (gg) {
-                    float gv[ChunkOps<T>::N];
-                    ChunkOps<T>::unpack(*(const i32x4*)(gg + oaddr[s]), gv);
-#pragma unroll
-                    for (int e = 0; e < ChunkOps<T>::N; ++e) f[e] = gv[e] > 0.f ? f[e] : 0.f;
-                }
-                if (rg) {
-                    float rv[ChunkOps<T>::N];
-                    ChunkOps<T>::unpack(*(const i32x4*)(rg + oaddr[s]), rv);
-#pragma unroll
-                    for (int e = 0; e < ChunkOps<T>::N; ++e) f[e] += rv[e];
-                }
-                if (p.relu)
-#pragma unroll
-                    for (int e = 0; e < ChunkOps<T>::N; ++e) f[e] = fmaxf(f[e], 0.f);
-                outv[s] = ChunkOps<T>::pack(f);
-            }
-        }
-        ERF_LDS_BARRIER();                 // staging consumed: the buffer may take tile k+2
-
-        dma_tile<T, C, NW, KI>(p, tile_geo(p, tile + 2 * G), xg, smem + boff, wave, lane);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");      // this wave's share of tile k+1 has landed
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (oaddr[s] >= 0) *(i32x4*)(yg + oaddr[s]) = outv[s];
-        asm volatile("s_barrier" ::: "memory");                          // ... and everyone else's
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
-}
-
-
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 template <typename T, int C, int WM, int WN, int M, int MAXK>
@@ -544,83 +251,16 @@ static int launch_cfg(Conv1dParams p, int N, int H, int W, int axis, hipStream_t
     return erf_check_launch();
 }
 
-// Tile shape shared by both generations: Tm a power of two, at most the lattice points per residue
-// class (min 2), at most M/16; the row-major axis (H) keeps Tm <= 8 so the contiguous runs along W stay long.
-static bool plan_tiles(Conv1dParams& p, int N, int H, int W, int axis, int M, int CH) {
-    const int d = p.d;
-    if (axis == 0) {
-        p.A = H; p.Bn = W; p.nimg = N; p.img_stride = (long long)H * W; p.stride_u = d * W; p.stride_v = 1;
-    } else {
-        p.A = W; p.Bn = N * H; p.nimg = 1; p.img_stride = 0; p.stride_u = d; p.stride_v = W;
-    }
-    const int npts = (p.A + d - 1) / d;
-    const int tm_max = axis == 0 ? 8 : 32;
-    int Tm = 2;
-    while (Tm * 2 <= npts && Tm * 2 <= tm_max && Tm * 2 <= M / 16) Tm *= 2;
-    const int Tn = M / Tm;
-    p.Tm = Tm; p.Tn = Tn; p.log2Tn = ilog2(Tn);
-    p.total_chunks = (Tm + 2) * Tn * CH;
-    p.CA = (npts + Tm - 1) / Tm;
-    p.CB = (p.Bn + Tn - 1) / Tn;
-    const long long nt = (long long)p.nimg * d * p.CA * p.CB;
-    if (nt > 0x3FFFFFFF) return false;
-    p.ntiles = (int)nt;
-    return true;
-}
-
-template <typename T, int C, int WM, int WN, int M, int KI>
-static int launch_dma(Conv1dParams p, int N, int H, int W, int axis, hipStream_t stream) {
-    constexpr int CH = C / Elem<T>::EPC;
-    constexpr int NW = WM * WN;
-    constexpr int OCC = NW <= 4 ? 2 : 1;
-    constexpr size_t lds = 2 * (size_t)KI * NW * 1024;
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!plan_tiles(p, N, H, W, axis, M, CH)) return ERF_EUNSUPPORTED;
-    if (p.total_chunks > KI * NW * 64) return ERF_EUNSUPPORTED;
-    int wg_per_cu = (int)(160 * 1024 / lds);
-    if (wg_per_cu > OCC) wg_per_cu = OCC;
-    int grid = 256 * wg_per_cu;
-    if (grid > p.ntiles) grid = p.ntiles;
-    auto kern = conv1d_dma_kernel<T, C, WM, WN, M, KI, OCC>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ERF_ELAUNCH;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, stream, p);
-    return erf_check_launch();
-}
-
 int conv1d_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, const void* residual,
                   const void* gate, int dtype, int N, int H, int W, int C, int axis, int dilation, int relu, hipStream_t stream) {
     Conv1dParams p{};
     p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual; p.gate = gate;
     p.d = dilation; p.relu = relu;
     if ((long long)N * H * W >= (1LL << 31)) return ERF_EUNSUPPORTED;
-    static const int force_v1 = getenv("ERF_CONV1D_V1") ? atoi(getenv("ERF_CONV1D_V1")) : 0;
-    int rc = ERF_EUNSUPPORTED;
-    if (!force_v1) {
-        if (dtype == 1) {
-            if (C == 128) {
-                rc = launch_dma<bf16raw, 128, 1, 4, 128, 10>(p, N, H, W, axis, stream);
-                if (rc == ERF_EUNSUPPORTED) rc = launch_dma<bf16raw, 128, 1, 4, 128, 12>(p, N, H, W, axis, stream);
-            } else if (C == 64) {
-                rc = launch_dma<bf16raw, 64, 4, 1, 128, 5>(p, N, H, W, axis, stream);
-                if (rc == ERF_EUNSUPPORTED) rc = launch_dma<bf16raw, 64, 4, 1, 128, 6>(p, N, H, W, axis, stream);
-            } else if (C == 16) {
-                rc = launch_dma<bf16raw, 16, 4, 1, 512, 5>(p, N, H, W, axis, stream);
-            }
-        } else {
-            if (C == 128) {
-                rc = launch_dma<float, 128, 1, 8, 128, 10>(p, N, H, W, axis, stream);
-            } else if (C == 64) {
-                rc = launch_dma<float, 64, 1, 4, 128, 10>(p, N, H, W, axis, stream);
-                if (rc == ERF_EUNSUPPORTED) rc = launch_dma<float, 64, 1, 4, 128, 12>(p, N, H, W, axis, stream);
-            } else if (C == 16) {
-                rc = launch_dma<float, 16, 4, 1, 512, 10>(p, N, H, W, axis, stream);
-            }
-        }
-        if (rc != ERF_EUNSUPPORTED) return rc;
-    }
+    // buffer-addressed DMA kernel first; the register-staged kernel below takes what it declines
+    const int rc = conv1d_buf_launch(x, y, packed, scale, shift, residual, gate, nullptr, nullptr, dtype, N, H, W, C, axis, dilation,
+                                     relu, stream);
+    if (rc != ERF_EUNSUPPORTED) return rc;
     if (dtype == 1) {
         if (C == 128) return launch_cfg<bf16raw, 128, 1, 4, 128, 12>(p, N, H, W, axis, stream);
         if (C == 64) return launch_cfg<bf16raw, 64, 4, 1, 128, 8>(p, N, H, W, axis, stream);

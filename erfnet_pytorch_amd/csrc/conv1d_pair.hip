@@ -410,7 +410,9 @@ void conv1d_pair_kernel(const PairParams p) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");      // this wave's share of tile k+1 has landed
 #pragma unroll
         for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[s]), rs_y, ooff[s], out_soff, 0);
-        asm volatile("s_barrier" ::: "memory");                          // ... and everyone else's
+        // the data registers of a 16-byte buffer store must not be rewritten in the cycles right after its issue
+        // (the compiler does not guard stores with an SGPR offset): pause before anything else runs
+        asm volatile("s_nop 7\n\ts_barrier" ::: "memory");             // ... and everyone else's
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
 #endif

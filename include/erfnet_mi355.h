@@ -227,6 +227,23 @@ int erf_upsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, int
 int erf_output_conv_wgrad(const void* x, const void* patches, float* dw, int dtype, int N, int Hin, int Win, int nc,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused producers of the training step (no counterpart call in the reference: torch launches the
+ * convolution, the BatchNorm statistics and the bias-gradient reduction as separate kernels) -------
+ * erf_conv1d_factorized_bn: z = conv(x) + bias (train/erfnet.py:60-61 / :68-69, the 1x3 convolution and the
+ *   BatchNorm that follows it) -- the per-channel sum and sum of squares of z are accumulated in the
+ *   convolution's epilogue and finalised exactly like erf_bn_stats_finalize (same outputs, same workspace
+ *   size erf_bn_workspace_bytes(C)).
+ * erf_conv1d_dgrad_bias: erf_conv1d_dgrad plus dbias[c] = sum_p dx[p][c], the bias gradient of the
+ *   convolution whose output gradient dx is.
+ * Both return ERF_EUNSUPPORTED without launching when the shape needs the generic kernels: issue the two
+ * separate calls then. */
+int erf_conv1d_factorized_bn(const void* x, void* z, const void* packed, const float* bias, int dtype, int N, int H, int W,
+                             int C, int axis, int dilation, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                             float* shift, void* workspace, void* stream);
+int erf_conv1d_dgrad_bias(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual, int dtype,
+                          int N, int H, int W, int C, int axis, int dilation, float* dbias, void* workspace, void* stream);
+
 /* ---- classifier head of the ImageNet pre-training variant, train/erfnet_imagenet.py:97-120 ----
  * Features.forward after the encoder: MaxPool2d(2, stride 2) -> AvgPool2d(14, 1, 0) on the 28x28 map
  * -> view(N, C); Classifier: Linear(C, K).  x: NHWC [N,H,W,C] (H = W = 28 in the reference; any even
