@@ -88,6 +88,10 @@ int erf_downsampler(const void* x, void* y, const void* packed, const float* sca
     if (!x || !y || !packed || !dtype_ok(dtype) || N <= 0 || Hin <= 0 || Win <= 0) return ERF_EINVAL;
     if ((Hin | Win) & 1) return ERF_EINVAL;      // the reference's cat() needs even H, W as well
     if (!((Cin == 16 && Cout == 64) || (Cin == 64 && Cout == 128))) return ERF_EUNSUPPORTED;
+    {
+        const int rc = down_launch(x, y, packed, scale, shift, dtype, N, Hin, Win, Cin, Cout, relu, (hipStream_t)stream);
+        if (rc != ERF_EUNSUPPORTED) return rc;
+    }
     GConvParams p{};
     p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift; p.res = nullptr;
     p.N = N; p.Hin = Hin; p.Win = Win; p.ldx = Cin; p.xoff = 0; p.Hb = Hin / 2; p.Wb = Win / 2; p.Hout = Hin / 2; p.Wout = Win / 2;
