@@ -150,6 +150,10 @@ int erf_upsampler_convT3x3s2(const void* x, void* y, const void* packed, const f
                              int N, int Hin, int Win, int Cin, int Cout, int relu, void* stream) {
     if (!x || !y || !packed || !dtype_ok(dtype) || N <= 0 || Hin <= 0 || Win <= 0) return ERF_EINVAL;
     if (!((Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 16))) return ERF_EUNSUPPORTED;
+    {
+        const int rc = up_launch(x, y, packed, scale, shift, dtype, N, Hin, Win, Cin, Cout, relu, (hipStream_t)stream);
+        if (rc != ERF_EUNSUPPORTED) return rc;
+    }
     GConvParams p{};
     p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift; p.res = nullptr;
     p.N = N; p.Hin = Hin; p.Win = Win; p.ldx = Cin; p.xoff = 0; p.Hb = Hin; p.Wb = Win; p.Hout = 2 * Hin; p.Wout = 2 * Win;

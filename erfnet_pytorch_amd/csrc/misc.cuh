@@ -6,6 +6,9 @@ int stem_launch(const void* x, int x_dtype, void* y, const float* w, const float
 // Whole DownsamplerBlock in one launch (down.hip, bf16); ERF_EUNSUPPORTED: use the gather conv + pool_affine pair.
 int down_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, int dtype, int N, int Hin,
                 int Win, int Cin, int Cout, int relu, hipStream_t stream);
+// Whole UpsamplerBlock in one launch (up.hip, bf16); ERF_EUNSUPPORTED: use the gather conv.
+int up_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, int dtype, int N, int Hin, int Win,
+              int Cin, int Cout, int relu, hipStream_t stream);
 int pool_affine_launch(const void* x, void* y, const float* scale, const float* shift, int dtype, int N, int Hin, int Win,
                        int Cin, int ldy, int yoff, int relu, hipStream_t stream);
 int transpose_launch(const void* src, int sdt, void* dst, int ddt, int N, long long R, long long Cc, hipStream_t stream);
