@@ -13,14 +13,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T*
                                                    const float* __restrict__ w, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int N, int Hin, int Win, int relu,
                                                    float* __restrict__ raw_out) {
-    __shared__ float sw[13 * 27 + 1];
-    __shared__ float ssc[16], ssh[16];
-    for (int i = threadIdx.x; i < 13 * 27; i += blockDim.x) sw[i] = w[i];
-    if (threadIdx.x < 16) {
-        ssc[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
-        ssh[threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
-    }
-    __syncthreads();
+    // The 351 weights and 32 affine coefficients are read at wave-uniform, compile-time offsets, i.e. through the
+    // scalar cache into SGPRs: every FMA takes its weight as a scalar operand (no LDS traffic, no VGPRs).
     const int Ho = Hin >> 1, Wo = Win >> 1;
     const long long P = (long long)N * Ho * Wo;
     const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,7 +42,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T*
     for (int co = 0; co < 13; ++co) {
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < 27; ++k) a = fmaf(sw[co * 27 + k], in[k], a);
+        for (int k = 0; k < 27; ++k) a = fmaf(w[co * 27 + k], in[k], a);
         out[co] = a;
     }
     // max-pool window (2ho..2ho+1, 2wo..2wo+1) = taps (th,tw) in {1,2}^2 of the 3x3 patch
@@ -61,7 +55,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T*
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        float v = out[c] * ssc[c] + ssh[c];
+        float v = out[c] * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
         out[c] = relu ? fmaxf(v, 0.f) : v;
     }
     T* yp = y + pix * 16;
@@ -209,20 +203,49 @@ int argmax_launch(const void* z, int dtype, void* lab, int label_bytes, int N, i
 template <typename TP, typename TLB>
 __global__ __launch_bounds__(256) void iou_hist_kernel(const TP* __restrict__ pred, const TLB* __restrict__ label,
                                                        long long count, int nc, unsigned long long* __restrict__ hist) {
-    __shared__ unsigned int sh[32 * 32 + 1];
+    // one private copy of the counters per wave (less contention on the LDS atomics); a thread takes 8 consecutive
+    // pixels per trip (vector loads) and merges runs of equal (label, prediction) pairs before touching LDS --
+    // label maps are piecewise constant, so most trips end in one or two atomics
+    __shared__ unsigned int sh[4][32 * 32 + 1];
     const int cells = nc * nc + 1;
-    for (int i = threadIdx.x; i < cells; i += blockDim.x) sh[i] = 0;
+    for (int i = threadIdx.x; i < 4 * (32 * 32 + 1); i += blockDim.x) (&sh[0][0])[i] = 0;
     __syncthreads();
+    unsigned int* mine = sh[threadIdx.x >> 6];
+    const long long groups = count >> 3;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const long long g = (long long)label[i];
-        const long long p = (long long)pred[i];
-        const bool ok = g >= 0 && g < nc && p >= 0 && p < nc;
-        atomicAdd(&sh[ok ? (int)(g * nc + p) : nc * nc], 1u);
+    for (long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += stride) {
+        TP pv[8];
+        TLB lv[8];
+        if constexpr (sizeof(TP) == 1) *(unsigned long long*)pv = *(const unsigned long long*)(pred + gidx * 8);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) *(i32x4*)(pv + k) = *(const i32x4*)(pred + gidx * 8 + k);
+        }
+        if constexpr (sizeof(TLB) == 1) *(unsigned long long*)lv = *(const unsigned long long*)(label + gidx * 8);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) *(i32x4*)(lv + k) = *(const i32x4*)(label + gidx * 8 + k);
+        }
+        int prev = -1;
+        unsigned int run = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long g = (long long)lv[k], q = (long long)pv[k];
+            const int key = (g >= 0 && g < nc && q >= 0 && q < nc) ? (int)(g * nc + q) : nc * nc;
+            if (key == prev) { ++run; continue; }
+            if (run) atomicAdd(&mine[prev], run);
+            prev = key; run = 1;
+        }
+        atomicAdd(&mine[prev], run);
+    }
+    // tail (count not a multiple of 8)
+    for (long long i = groups * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const long long g = (long long)label[i], q = (long long)pred[i];
+        atomicAdd(&mine[(g >= 0 && g < nc && q >= 0 && q < nc) ? (int)(g * nc + q) : nc * nc], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < cells; i += blockDim.x) {
-        const unsigned int v = sh[i];
+        const unsigned int v = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i];
         if (v) atomicAdd(&hist[i], (unsigned long long)v);
     }
 }
@@ -231,8 +254,9 @@ int iou_hist_launch(const void* pred, int pred_bytes, const void* label, int lab
                     long long* hist, hipStream_t stream) {
     if (nc < 1 || nc > 32 || count < 0) return ERF_EINVAL;
     if (count == 0) return ERF_OK;
-    long long blocks = (count + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 2048) blocks = 2048;
+    long long blocks = (count + 256 * 8 * 4 - 1) / (256 * 8 * 4);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
 #define IH(TP, TLB) hipLaunchKernelGGL((iou_hist_kernel<TP, TLB>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TP*)pred, (const TLB*)label, count, nc, (unsigned long long*)hist)
     if (pred_bytes == 1 && label_bytes == 8) IH(unsigned char, long long);
     else if (pred_bytes == 8 && label_bytes == 8) IH(long long, long long);
