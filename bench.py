@@ -178,11 +178,17 @@ def roofline_infer(model, x, dtype_name):
         name = "conv1d_dma_kernel<float,128> (factorized conv, 128-channel blocks)"
     run()
     torch.cuda.synchronize()
+    # replayed from a HIP graph so that the events bracket back-to-back kernels, not host launch gaps
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = 10
     e0.record()
     for _ in range(reps):
-        run()
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
     avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * len(plan))
