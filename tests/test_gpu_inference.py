@@ -246,3 +246,45 @@ def test_iou_eval_exact_vs_golden_and_oracle():
     tp, fp, fn = O.iou_counts(pred, lab, 20)
     assert torch.equal(ev.tp, tp) and torch.equal(ev.fp, fp) and torch.equal(ev.fn, fn)
     assert int(ev.confusion().sum()) == pred.numel()
+
+
+@pytest.mark.parametrize("cin,cout,shape", [
+    (64, 128, (2, 64, 26, 44)), (64, 128, (1, 64, 8, 32)), (64, 128, (1, 64, 128, 256)),
+    (16, 64, (2, 16, 38, 52)), (16, 64, (1, 16, 16, 20)), (16, 64, (1, 16, 256, 512)),
+])
+def test_downsampler_one_launch_kernel_edges(cin, cout, shape):
+    """bf16 DownsamplerBlock kernel on maps whose halved size is no multiple of the tile (R rows x 16 columns):
+    zero padding at the top / left, clipped tiles at the bottom / right, pooled half, affine + ReLU."""
+    from erfnet_pytorch_amd import ops
+    seed = 500 + cin
+    x = (activations(shape, seed) - 0.4).bfloat16().float()
+    w = S.fill_tensor("d.conv.weight", (cout - cin, cin, 3, 3), salt=seed).bfloat16().float()
+    sc = S.fill_tensor("d.bn.weight", (cout,), salt=seed)
+    sh = S.fill_tensor("d.bn.bias", (cout,), salt=seed)
+    ref = torch.cat([F.conv2d(x, w, None, stride=2, padding=1), F.max_pool2d(x, 2, stride=2)], 1)
+    ref = F.relu(ref * sc[None, :, None, None] + sh[None, :, None, None])
+    code = ops.dt(torch.empty(0, dtype=torch.bfloat16))
+    y = ops.downsampler(_nhwc(x, torch.bfloat16), ops.pack_downsampler(w.to(_dev()), code), sc.to(_dev()), sh.to(_dev()), cout)
+    torch.cuda.synchronize()
+    assert rel_err(_back(y), ref) <= 1e-2            # bf16 output rounding only: inputs and weights are bf16-exact
+
+
+@pytest.mark.parametrize("cin,cout,shape", [
+    (128, 64, (2, 128, 13, 22)), (128, 64, (1, 128, 4, 16)), (128, 64, (1, 128, 64, 128)),
+    (64, 16, (2, 64, 19, 26)), (64, 16, (1, 64, 8, 16)), (64, 16, (1, 64, 128, 256)),
+])
+def test_upsampler_one_launch_kernel_edges(cin, cout, shape):
+    """bf16 UpsamplerBlock kernel: parity phases, halo row / column beyond the image (zero contribution), clipped tiles."""
+    from erfnet_pytorch_amd import ops
+    seed = 600 + cin
+    x = (activations(shape, seed) - 0.4).bfloat16().float()
+    w = S.fill_tensor("u.conv.weight", (cin, cout, 3, 3), salt=seed).bfloat16().float()
+    sc = S.fill_tensor("u.bn.weight", (cout,), salt=seed)
+    sh = S.fill_tensor("u.bn.bias", (cout,), salt=seed)
+    ref = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
+    ref = F.relu(ref * sc[None, :, None, None] + sh[None, :, None, None])
+    code = ops.dt(torch.empty(0, dtype=torch.bfloat16))
+    y = ops.upsampler(_nhwc(x, torch.bfloat16), ops.pack_upsampler(w.to(_dev()), code), sc.to(_dev()), sh.to(_dev()), cout)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (shape[0], 2 * shape[2], 2 * shape[3], cout)
+    assert rel_err(_back(y), ref) <= 1e-2
