@@ -25,25 +25,44 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ 
     f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
     if (MODE == 1) { mu = *(const f32x4*)(mean + c); is = *(const f32x4*)(invstd + c); }
     if (pl < PL) {
-        for (long long p = (long long)blockIdx.x * PL + pl; p < P; p += (long long)gridDim.x * PL) {
-            f32x4 v = load4<T>(a + p * C + c);
-            if (MODE == 0) {
+        // U pixels per trip: all their loads are issued before the first use, which is what keeps enough bytes in
+        // flight with only a few waves per CU (the reduction is one pass over up to three tensors)
+        constexpr int U = 4;
+        const long long step = (long long)gridDim.x * PL;
+        for (long long p0 = (long long)blockIdx.x * PL + pl; p0 < P; p0 += U * step) {
+            f32x4 v[U], gt[U], zz[U];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)v[e] * (double)v[e]; }
-            } else {
-                if (gate) {
-                    const f32x4 gt = load4<T>(gate + p * C + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gt[e] > 0.f ? v[e] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const long long p = p0 + u * step;
+                const bool live = p < P;
+                const long long pp = live ? p : p0;
+                v[u] = load4<T>(a + pp * C + c);
+                if (!live) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (MODE == 1) {
+                    gt[u] = gate ? load4<T>(gate + pp * C + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    zz[u] = load4<T>(z + pp * C + c);
                 }
-                if (mask) {
-                    const f32x4 mk = *(const f32x4*)(mask + (p / HW) * C + c);
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= mk[e];
+            for (int u = 0; u < U; ++u) {
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s0[e] += (double)v[u][e]; s1[e] += (double)v[u][e] * (double)v[u][e]; }
+                } else {
+                    const long long p = p0 + u * step < P ? p0 + u * step : p0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = gt[u][e] > 0.f ? v[u][e] : 0.f;
+                    if (mask) {
+                        const f32x4 mk = *(const f32x4*)(mask + (p / HW) * C + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[u][e] *= mk[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s0[e] += (double)v[u][e];
+                        s1[e] += (double)(v[u][e] * ((zz[u][e] - mu[e]) * is[e]));
+                    }
                 }
-                const f32x4 zz = load4<T>(z + p * C + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s0[e] += (double)v[e]; s1[e] += (double)(v[e] * ((zz[e] - mu[e]) * is[e])); }
             }
         }
     }
@@ -84,22 +103,22 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     const int c = threadIdx.x % C, part = threadIdx.x / C;
     double a = 0, b = 0;
     if (part < nparts) {
-        // four independent chains keep the loads in flight; the order of the additions is fixed
-        double a4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0};
+        // eight independent chains keep the loads in flight; the order of the additions is fixed
+        double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int g = part;
-        for (; g + 3 * nparts < groups; g += 4 * nparts) {
+        for (; g + 7 * nparts < groups; g += 8 * nparts) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a4[u] += partials[(long long)(g + u * nparts) * 2 * C + c];
-                b4[u] += partials[(long long)(g + u * nparts) * 2 * C + C + c];
+            for (int u = 0; u < 8; ++u) {
+                a8[u] += partials[(long long)(g + u * nparts) * 2 * C + c];
+                b8[u] += partials[(long long)(g + u * nparts) * 2 * C + C + c];
             }
         }
         for (; g < groups; g += nparts) {
-            a4[0] += partials[(long long)g * 2 * C + c];
-            b4[0] += partials[(long long)g * 2 * C + C + c];
+            a8[0] += partials[(long long)g * 2 * C + c];
+            b8[0] += partials[(long long)g * 2 * C + C + c];
         }
-        a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+        a = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        b = ((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7]));
     }
     sh[threadIdx.x] = a;
     sh[FIN_THREADS + threadIdx.x] = b;
