@@ -103,9 +103,15 @@ SIGNATURES = {
     "erf_stem_wgrad": (I, [P, P, P, I, I, I, I, P, c_size_t, P]),
     "erf_upsampler_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
     "erf_output_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P]),
+    "erf_pointwise_grad_channels": (I, [I]),
+    "erf_pointwise_grad_nhwc": (I, [P, I, P, I, I, I, I, I, P]),
+    "erf_pointwise_dgrad_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_pointwise_dgrad_pack": (I, [P, P, I, I, I, P]),
+    "erf_pointwise_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "erf_pointwise_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
 }
 # entry points whose int return value is data, not a status
-_PLAIN_INT = {"erf_version", "erf_output_conv_patch_channels"}
+_PLAIN_INT = {"erf_version", "erf_output_conv_patch_channels", "erf_pointwise_grad_channels"}
 
 _fn = {}
 for _name, (_res, _args) in SIGNATURES.items():

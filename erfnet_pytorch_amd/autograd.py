@@ -391,6 +391,45 @@ class _OutConvFn(torch.autograd.Function):
         return (ops.to_nchw_view(dxh),) + sk.ret(dw, db) + (None, None)
 
 
+# --------------------------------------------------------------------------- Encoder.output_conv (encoder-only training)
+class _PointwiseFn(torch.autograd.Function):
+    """1x1 convolution 128 -> num_classes on the encoder's features (reference train/erfnet.py:96-97)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, logits_f32, mod=None):
+        xh = ops.to_nhwc(x)
+        code = ops.dt(xh)
+        nc = w.shape[0]
+        logits = ops.pointwise(xh, ops.pack_pointwise(w.flatten(1), code), _f32(b), nc, out_f32=logits_f32)
+        ctx.save_for_backward(xh, w)
+        ctx.mod = mod
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        xh, w = ctx.saved_tensors
+        code, dev = ops.dt(xh), xh.device
+        n, h, wd, cin = xh.shape
+        nc = w.shape[0]
+        glogits = glogits.contiguous()
+        ld = query("erf_pointwise_grad_channels", nc)
+        g = torch.empty((n, h, wd, ld), dtype=xh.dtype, device=dev)
+        call("erf_pointwise_grad_nhwc", glogits.data_ptr(), ops.dt(glogits), g.data_ptr(), code, n, h, wd, nc, _stream())
+        sk = _Sink(ctx.mod)
+        db = sk.out("bias", (nc,), dev)
+        db.copy_(channel_sum(g)[:nc])
+        dw = sk.out("weight", w.shape, dev)
+        nb = query("erf_wgrad_workspace_bytes", nc, cin, 1, n * h * wd)
+        ws = _ws(nb, dev)
+        call("erf_pointwise_wgrad", xh.data_ptr(), g.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, nc, ws.data_ptr(), nb,
+             _stream())
+        pk = torch.empty(query("erf_pointwise_dgrad_packed_bytes", code, cin, nc), dtype=torch.uint8, device=dev)
+        call("erf_pointwise_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, cin, nc, _stream())
+        dxh = torch.empty_like(xh)
+        call("erf_pointwise_dgrad", g.data_ptr(), dxh.data_ptr(), pk.data_ptr(), code, n, h, wd, cin, nc, _stream())
+        return (ops.to_nchw_view(dxh),) + sk.ret(dw, db) + (None, None)
+
+
 # --------------------------------------------------------------------------- dispatch from the modules
 def block_forward(mod, x):
     from . import erfnet as E
@@ -411,12 +450,12 @@ def _compute_code(owner, x):
 
 
 def encoder_forward(enc, x, predict=False, code=None):
-    if predict:
-        raise NotImplementedError("training through Encoder.output_conv (only_encode=True) is not built yet")
     enc.initial_block.__dict__["_erf_code"] = _compute_code(enc, x) if code is None else code
     y = block_forward(enc.initial_block, x)
     for layer in enc.layers:
         y = block_forward(layer, y)
+    if predict:
+        y = _PointwiseFn.apply(y, enc.output_conv.weight, enc.output_conv.bias, x.dtype == torch.float32, enc.output_conv)
     return y
 
 

@@ -291,6 +291,57 @@ int erf_output_conv_dgrad(const void* patches, void* dx, const void* packed_t, c
     return gconv_launch(p, dtype, ld, (hipStream_t)stream);
 }
 
+// ---- Encoder.output_conv (1x1, 128 -> nc): gradient of the encoder-only training pass
+int erf_pointwise_grad_channels(int nc) { return (nc + 15) / 16 * 16; }
+
+int erf_pointwise_grad_nhwc(const void* dlogits, int src_dtype, void* g, int dtype, int N, int H, int W, int nc, void* stream) {
+    if (!dlogits || !g || !dtype_ok(dtype) || !dtype_ok(src_dtype) || N <= 0 || H <= 0 || W <= 0 || nc < 1 || nc > 32)
+        return ERF_EINVAL;
+    const int ld = erf_pointwise_grad_channels(nc);
+    return patches_launch(dlogits, src_dtype, g, dtype, N, H, W, nc, ld, ld, (hipStream_t)stream, 1);
+}
+
+size_t erf_pointwise_dgrad_packed_bytes(int dtype, int Cin, int nc) {
+    if (!dtype_ok(dtype) || Cin != 128 || nc < 1 || nc > 32) return 0;
+    return (size_t)gconv_phase_chunks(Cin / 16, gconv_ksteps(dtype, erf_pointwise_grad_channels(nc), 1)) * 16;
+}
+
+int erf_pointwise_dgrad_pack(const float* w, void* packed, int dtype, int Cin, int nc, void* stream) {
+    if (!w || !packed || !dtype_ok(dtype) || Cin != 128 || nc < 1 || nc > 32) return ERF_EINVAL;
+    const int ld = erf_pointwise_grad_channels(nc);
+    PackParams p{};
+    p.src = w; p.dst = packed; p.cin = ld; p.cin_valid = nc; p.cout_virtual = Cin; p.ncp = NO_PHASES; p.nc_valid = Cin;
+    p.s_co = 1; p.s_ci = Cin; p.ntaps = 1; p.toff[0] = 0;                 // weight [nc][Cin]: rows of the transposed GEMM = Cin
+    p.ct = Cin / 16; p.ksteps = gconv_ksteps(dtype, ld, 1);
+    return pack_launch(p, dtype, (hipStream_t)stream);
+}
+
+int erf_pointwise_dgrad(const void* g, void* dx, const void* packed_t, int dtype, int N, int H, int W, int Cin, int nc,
+                        void* stream) {
+    if (!g || !dx || !packed_t || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || nc < 1 || nc > 32) return ERF_EINVAL;
+    if (Cin != 128) return ERF_EUNSUPPORTED;
+    const int ld = erf_pointwise_grad_channels(nc);
+    GConvParams p{};
+    p.x = g; p.y = dx; p.w = packed_t;
+    p.N = N; p.Hin = H; p.Win = W; p.ldx = ld; p.Hb = H; p.Wb = W; p.Hout = H; p.Wout = W; p.ldy = Cin; p.Cout = Cin;
+    p.Si = 1; p.So = 1; p.nphase = 1;
+    p.ph[0].ntaps = 1; p.ph[0].ksteps = gconv_ksteps(dtype, ld, 1);
+    return gconv_launch(p, dtype, ld, (hipStream_t)stream);
+}
+
+int erf_pointwise_wgrad(const void* x, const void* g, float* dw, int dtype, int N, int H, int W, int Cin, int nc,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !g || !dw || !workspace || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || nc < 1 || nc > 32) return ERF_EINVAL;
+    if (Cin != 128) return ERF_EUNSUPPORTED;
+    const int ld = erf_pointwise_grad_channels(nc);
+    GConvParams geo{};
+    geo.x = x; geo.N = N; geo.Hin = H; geo.Win = W; geo.ldx = Cin; geo.Hb = H; geo.Wb = W; geo.Hout = H; geo.Wout = W;
+    geo.Si = 1; geo.So = 1; geo.nphase = 1; geo.ph[0].ntaps = 1;
+    PackParams m{};
+    m.cin = Cin; m.cout_virtual = nc; m.ncp = NO_PHASES; m.nc_valid = nc; m.s_co = Cin; m.s_ci = 1; m.ntaps = 1;
+    return wgrad_launch(geo, g, ld, 0, nc, Cin, &m, dw, (float*)workspace, workspace_bytes, dtype, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ weight gradients
 size_t erf_wgrad_workspace_bytes(int rows, int cin, int taps_per_phase, long long base_pixels) {
     return wgrad_workspace_bytes(rows, cin, taps_per_phase, base_pixels);

@@ -22,6 +22,7 @@ int gconv_launch(const GConvParams& p, int dtype, int cin, hipStream_t stream) {
     GC_CASE(16, 2, 4)
     GC_CASE(16, 3, 4)
     GC_CASE(16, 4, 4)
+    GC_CASE(16, 8, 2)
     GC_CASE(32, 1, 4)
     GC_CASE(32, 8, 2)
     GC_CASE(48, 1, 4)

@@ -35,7 +35,7 @@ int adam_launch(float* p, const float* g, float* m, float* v, long long n, doubl
 int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, double momentum, double wd, int first,
                double gscale, hipStream_t stream);
 int patches_launch(const void* dl, int src_dtype, void* out, int dtype, int N, int H, int W, int nc, int ncp, int ld,
-                   hipStream_t stream);
+                   hipStream_t stream, int patch_edge = 2);
 int image_pad_launch(const void* x, int src_dtype, void* out, int dtype, int N, long long HW, int cpad, hipStream_t stream);
 
 // ---- weight gradients (wgrad.hip): dW[row][tap][ci] = sum_pixels dz[out pixel][row] * x[in pixel(tap)][ci]

@@ -600,7 +600,8 @@ int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, dou
 // dlogits NCHW [N,nc,2H,2W] -> "patch" NHWC [N,H,W,ld] (channel = 4*class + phase, phase = 2a+b
 // the position inside the 2x2 output patch; channels >= 4*nc zero), the layout output_conv's
 // backward GEMMs take.  `ncp` = ld / 4.
-template <typename TS, typename T>
+// S = 1 is the degenerate patch: channel = class (Encoder.output_conv, the 1x1 head).
+template <typename TS, typename T, int S>
 __global__ __launch_bounds__(256) void patches_kernel(const TS* __restrict__ dl, T* __restrict__ out, int N, int H, int W,
                                                       int nc, int ncp, int ld) {
     // one block = 64 consecutive input pixels of one image row-major range; tile[px][v] in LDS
@@ -613,13 +614,13 @@ __global__ __launch_bounds__(256) void patches_kernel(const TS* __restrict__ dl,
         const int px = id & 63, v = id >> 6;
         const long long pix = pix0 + px;
         float val = 0.f;
-        const int cls = v >> 2, ph = v & 3;
+        const int cls = S == 2 ? v >> 2 : v, ph = S == 2 ? v & 3 : 0;
         if (pix < P && cls < nc) {
             const int j = (int)(pix % W);
             const long long rest = pix / W;
             const int i = (int)(rest % H);
             const int n = (int)(rest / H);
-            val = Elem<TS>::ld(dl + (((long long)n * nc + cls) * (2 * H) + 2 * i + (ph >> 1)) * (2 * W) + 2 * j + (ph & 1));
+            val = Elem<TS>::ld(dl + (((long long)n * nc + cls) * (S * H) + S * i + (ph >> 1)) * (S * W) + S * j + (ph & 1));
         }
         tile[px * ldt + v] = val;
     }
@@ -632,17 +633,19 @@ __global__ __launch_bounds__(256) void patches_kernel(const TS* __restrict__ dl,
 }
 
 int patches_launch(const void* dl, int src_dtype, void* out, int dtype, int N, int H, int W, int nc, int ncp, int ld,
-                   hipStream_t stream) {
+                   hipStream_t stream, int patch_edge) {
     const long long blocks = ((long long)N * H * W + 63) / 64;
-    if (blocks > 0x7FFFFFFFLL) return ERF_EINVAL;
+    if (blocks > 0x7FFFFFFFLL || (patch_edge != 1 && patch_edge != 2)) return ERF_EINVAL;
     const size_t lds = (size_t)64 * (ld + 1) * sizeof(float);
-#define PK(TS, T) hipLaunchKernelGGL((patches_kernel<TS, T>), dim3((unsigned)blocks), dim3(256), lds, stream, (const TS*)dl, (T*)out, N, H, W, nc, ncp, ld)
+#define PK2(TS, T, S) hipLaunchKernelGGL((patches_kernel<TS, T, S>), dim3((unsigned)blocks), dim3(256), lds, stream, (const TS*)dl, (T*)out, N, H, W, nc, ncp, ld)
+#define PK(TS, T) do { if (patch_edge == 2) PK2(TS, T, 2); else PK2(TS, T, 1); } while (0)
     if (src_dtype == 0 && dtype == 0) PK(float, float);
     else if (src_dtype == 0 && dtype == 1) PK(float, bf16raw);
     else if (src_dtype == 1 && dtype == 1) PK(bf16raw, bf16raw);
     else if (src_dtype == 1 && dtype == 0) PK(bf16raw, float);
     else return ERF_EUNSUPPORTED;
 #undef PK
+#undef PK2
     return erf_check_launch();
 }
 

@@ -48,12 +48,15 @@ def _span(offsets, prefixes):
     return lo, hi
 
 
-def bucket_ranges(offsets) -> Tuple[List[Tuple[int, int]], List[Tuple[int, int]]]:
-    """(all-reduce buckets in backward-completion order, optimiser ranges) for an ERFNet arena."""
+def bucket_ranges(offsets, only_encode: bool = False) -> Tuple[List[Tuple[int, int]], List[Tuple[int, int]]]:
+    """(all-reduce buckets in backward-completion order, optimiser ranges) for an ERFNet arena.
+    `only_encode`: the encoder-only pass of train/main.py:203 -- the decoder takes no part, the 1x1 head does."""
     decoder = _span(offsets, ["decoder."])
     enc128 = _span(offsets, [f"encoder.layers.{i}." for i in range(6, 15)])
     enc_lo = _span(offsets, ["encoder.initial_block."] + [f"encoder.layers.{i}." for i in range(0, 6)])
     head = _span(offsets, ["encoder.output_conv."])
     if not (enc_lo[1] == enc128[0] and enc128[1] == head[0] and head[1] == decoder[0]):
         raise ValueError("parameter registration order differs from ERFNet's")
+    if only_encode:
+        return [(enc128[0], head[1]), enc_lo], [(enc_lo[0], head[1])]
     return [decoder, enc128, enc_lo], [(enc_lo[0], enc128[1]), decoder]

@@ -56,8 +56,12 @@ def _refresh_bank(bank, model, images):
 
 class Trainer:
     def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
-                 group=None, world_size=1, overlap=True):
+                 group=None, world_size=1, overlap=True, only_encode=False):
+        """`only_encode`: the first stage of the reference's recipe (train/main.py:495 `train(args, model, True)`,
+        :203 `model(inputs, only_encode=enc)`): logits from Encoder.output_conv at 1/8 resolution against targets of
+        that size; the decoder's parameters take no part and are left untouched."""
         self.model = model
+        self.only_encode = only_encode
         self.group, self.world = group, world_size
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_count = 0
@@ -85,7 +89,7 @@ class Trainer:
         for mname, mod in model.named_modules():
             own = {k: v for k, v in mod.named_parameters(recurse=True)} if isinstance(
                 mod, (E.DownsamplerBlock, E.UpsamplerBlock, E.non_bottleneck_1d)) else None
-            if own is None and mod is model.decoder.output_conv:
+            if own is None and (mod is model.decoder.output_conv or mod is model.encoder.output_conv):
                 own = dict(mod.named_parameters())
             if own is None:
                 continue
@@ -97,12 +101,14 @@ class Trainer:
 
         self._bank = None                               # packed factorized-conv weights, refreshed once per step
         # all-reduce buckets (backward-completion order) and the ranges Adam may touch
-        self.buckets, self.active = dp.bucket_ranges(self.offsets)
+        self.buckets, self.active = dp.bucket_ranges(self.offsets, only_encode)
         self._pending = []
         if self.overlap:
-            model.decoder.layers[0].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(0)
-            model.encoder.layers[6].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(1)
-            model.encoder.initial_block.__dict__["_erf_after_backward"] = lambda: self._launch_bucket(2)
+            last = len(self.buckets) - 1
+            if not only_encode:
+                model.decoder.layers[0].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(0)
+            model.encoder.layers[6].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(last - 1)
+            model.encoder.initial_block.__dict__["_erf_after_backward"] = lambda: self._launch_bucket(last)
 
     # -- collectives ------------------------------------------------------------------------
     def _launch_bucket(self, i):
@@ -132,7 +138,7 @@ class Trainer:
         if targets.dim() == 4:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
         self._refresh_packed(images)
-        outputs = self.model(images)
+        outputs = self.model(images, only_encode=True) if self.only_encode else self.model(images)
         loss = weighted_cross_entropy(outputs, targets, self.weight, self.group if self.world > 1 else None)
         loss.backward()
         self._reduce_gradients()

@@ -209,6 +209,21 @@ int erf_output_conv_dgrad_pack(const float* w, void* packed, int dtype, int nc, 
 int erf_output_conv_dgrad(const void* patches, void* dx, const void* packed_t, const void* gate, int dtype, int N, int Hin,
                           int Win, int nc, void* stream);
 
+/* ---- Encoder.output_conv backward: the encoder-only training pass (train/main.py:203 `model(inputs, only_encode=enc)`,
+ * train/erfnet.py:96-97 `if predict: output = self.output_conv(output)`; autograd of that 1x1 convolution).
+ * dlogits NCHW [N,nc,H,W] -> g NHWC [N,H,W,ldg], ldg = erf_pointwise_grad_channels(nc), channels >= nc zero;
+ * dx [N,H,W,Cin] = g x W (weights packed by erf_pointwise_dgrad_pack from the parameter's [nc,Cin,1,1] layout);
+ * dW [nc,Cin] fp32 = sum over pixels of g^T x (workspace: erf_wgrad_workspace_bytes(nc, Cin, 1, N*H*W));
+ * the bias gradient is erf_channel_sum(g)[:nc]. */
+int erf_pointwise_grad_channels(int nc);
+int erf_pointwise_grad_nhwc(const void* dlogits, int src_dtype, void* g, int dtype, int N, int H, int W, int nc, void* stream);
+size_t erf_pointwise_dgrad_packed_bytes(int dtype, int Cin, int nc);
+int erf_pointwise_dgrad_pack(const float* w, void* packed, int dtype, int Cin, int nc, void* stream);
+int erf_pointwise_dgrad(const void* g, void* dx, const void* packed_t, int dtype, int N, int H, int W, int Cin, int nc,
+                        void* stream);
+int erf_pointwise_wgrad(const void* x, const void* g, float* dw, int dtype, int N, int H, int W, int Cin, int nc,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- weight gradients: dW in the parameter's own torch layout, fp32, overwritten -----------
  * Contraction over pixels on MFMA tiles; per-workgroup partial tiles in `workspace`
  * (erf_wgrad_workspace_bytes(rows = output channels, cin, taps per phase, base pixels)), summed in a

@@ -240,12 +240,13 @@ def sgd_step(params, grads, bufs, lr=0.1, momentum=0.9, weight_decay=1e-4):
 
 # ----------------------------------------------------------------------------- training step helpers
 
-def train_step_grads(sd: SD, images, target, weight, masks=None, num_classes=20):
-    """One forward/backward in training mode.  Returns (loss, grads dict, new running stats, used masks)."""
+def train_step_grads(sd: SD, images, target, weight, masks=None, num_classes=20, only_encode=False):
+    """One forward/backward in training mode.  Returns (loss, grads dict, new running stats, used masks).
+    `only_encode`: the encoder stage of the recipe (train/main.py:203, `model(inputs, only_encode=enc)`)."""
     leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
             for k, v in sd.items()}
     st = RunState(training=True, dropout_masks=masks)
-    logits = erfnet(leaf, images, st)
+    logits = erfnet(leaf, images, st, only_encode=only_encode)
     loss = weighted_ce(logits, target, weight)
     loss.backward()
     grads = {k: v.grad for k, v in leaf.items() if isinstance(v, torch.Tensor) and v.requires_grad}

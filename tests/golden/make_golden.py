@@ -300,13 +300,69 @@ def g6_imagenet():
     np.savez_compressed(os.path.join(HERE, "g6_imagenet.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G7
+def g7_encoder_only():
+    """Encoder stage of the training recipe (train/main.py:203 with enc=True): the 1x1 head alone, then one
+    optimisation step of the whole network run with only_encode=True on targets at 1/8 resolution."""
+    out = {}
+    seed = 70
+    for nc in (20, 6):
+        seed += 1
+        mod = torch.nn.Conv2d(128, nc, 1, stride=1, padding=0, bias=True)
+        sd = S.fill_state_dict({"encoder.output_conv." + k: v for k, v in mod.state_dict().items()}, salt=seed)
+        mod.load_state_dict({k.rsplit(".", 1)[-1]: v for k, v in sd.items()})
+        x = activations((2, 128, 9, 14), seed).requires_grad_(True)
+        y = mod(x)
+        y.backward(upstream(y.shape, seed))
+        tag = f"head_{nc}"
+        out[tag + "__seed"] = np.array(seed, dtype=np.int64)
+        pack(out, tag + "_y", y)
+        pack(out, tag + "_dx", x.grad)
+        pack(out, tag + "_grad_weight", mod.weight.grad)
+        pack(out, tag + "_grad_bias", mod.bias.grad)
+    m = S.load_synthetic(ref_erfnet.ERFNet(20)).train()
+    crit = torch.nn.CrossEntropyLoss(torch.tensor(CITYSCAPES_WEIGHTS, dtype=torch.float32))
+    opt = torch.optim.Adam(m.parameters(), 5e-4, (0.9, 0.999), eps=1e-08, weight_decay=1e-4)
+    masks, handles = capture_masks(m)
+    torch.manual_seed(7)
+    x = S.synthetic_images(2, 64, 128, seed=77)
+    t = S.synthetic_labels(2, 8, 16, 20, seed=77)
+    y = m(x, only_encode=True)
+    opt.zero_grad()
+    loss = crit(y, t[:, 0])
+    loss.backward()
+    out["loss"] = np.array(loss.item(), dtype=np.float32)
+    out["masks__keys"] = np.array(sorted(masks.keys()))
+    for k in sorted(masks.keys()):
+        out["mask_" + k] = masks[k].numpy().copy()
+    out["param_names"] = np.array([k for k, _ in m.named_parameters()])
+    out["gradnorm"] = np.array([(-1.0 if p.grad is None else p.grad.double().norm().item()) for _, p in m.named_parameters()])
+    for k, p in m.named_parameters():
+        if p.grad is not None and ("encoder.output_conv" in k or "initial_block" in k or k.endswith("layers.7.conv3x1_1.weight")):
+            pack(out, "grad_" + k, p.grad)
+    before = [p.detach().clone() for _, p in m.named_parameters()]
+    opt.step()
+    out["paramsum"] = np.array([p.detach().double().sum().item() for _, p in m.named_parameters()])
+    out["paramabs"] = np.array([p.detach().double().abs().sum().item() for _, p in m.named_parameters()])
+    out["moved"] = np.array([float((p.detach() - b).abs().max().item()) for (_, p), b in zip(m.named_parameters(), before)])
+    pack(out, "logits", y)
+    for h in handles:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "g7_encoder_only.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # e.g. `make_golden.py g7_encoder_only`: regenerate the named sets only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_full_eval()
     g2_blocks()
     g3_loss()
     g4_iou()
     g5_train_steps()
     g6_imagenet()
+    g7_encoder_only()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

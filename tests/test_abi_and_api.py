@@ -102,3 +102,20 @@ def test_poly_lr_schedule():
     for e in (1, 2, 75, 150):
         assert poly_lr(5e-4, e, 150) == O.poly_lr(5e-4, e, 150)
     assert poly_lr(5e-4, 1, 150) == 5e-4
+
+
+def test_bucket_ranges_of_the_encoder_only_stage():
+    """Encoder stage (train/main.py:203, enc=True): buckets and optimiser range cover encoder + 1x1 head, never the decoder."""
+    from erfnet_pytorch_amd import dp
+    from oracle import erfnet_oracle as O
+    sd = O.synthetic_state(O.erfnet_template(20))
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    offsets, total = dp.arena_offsets([(k, sd[k].shape) for k in names])
+    full_b, full_a = dp.bucket_ranges(offsets)
+    enc_b, enc_a = dp.bucket_ranges(offsets, only_encode=True)
+    dec_lo = min(offsets[k][0] for k in names if k.startswith("decoder."))
+    head = offsets["encoder.output_conv.weight"]
+    assert enc_a == [(0, dec_lo)] and all(hi <= dec_lo for _, hi in enc_b)
+    assert sorted(enc_b)[0][0] == 0 and sorted(enc_b)[-1][1] == dec_lo and sorted(enc_b)[0][1] == sorted(enc_b)[1][0]
+    assert any(lo <= head[0] < hi for lo, hi in enc_b) and not any(lo <= head[0] < hi for lo, hi in full_a)
+    assert sum(hi - lo for lo, hi in full_b) + (dec_lo - head[0]) == total

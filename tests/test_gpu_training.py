@@ -385,6 +385,97 @@ def test_trainer_step_matches_golden_and_autograd():
         assert rel_err(params[k].detach().cpu(), p0) <= 1e-6, k
 
 
+@pytest.mark.parametrize("nc", [20, 6])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+def test_encoder_head_backward(nc, dtype, tol):
+    """Encoder.output_conv (1x1, 128 -> nc) forward + dx / dW / db against the reference's nn.Conv2d."""
+    from erfnet_pytorch_amd import autograd as ag
+    g = load("g7_encoder_only.npz")
+    tag = f"head_{nc}"
+    seed = int(g[tag + "__seed"])
+    w = S.fill_tensor("encoder.output_conv.weight", (nc, 128, 1, 1), salt=seed).to(DEV).requires_grad_(True)
+    b = S.fill_tensor("encoder.output_conv.bias", (nc,), salt=seed).to(DEV).requires_grad_(True)
+    x = activations((2, 128, 9, 14), seed).to(DEV, dtype).requires_grad_(True)
+    y = ag._PointwiseFn.apply(x, w, b, True)
+    assert y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (2, nc, 9, 14)
+    y.backward(upstream(tuple(y.shape), seed).to(DEV))
+    check_packed(g, tag + "_y", y.cpu(), tol)
+    check_packed(g, tag + "_dx", x.grad.float().cpu(), tol)
+    check_packed(g, tag + "_grad_weight", w.grad.cpu(), tol)
+    check_packed(g, tag + "_grad_bias", b.grad.cpu(), tol)
+
+
+def test_encoder_only_train_step_vs_golden():
+    """Stage 1 of the recipe (train/main.py:203, enc=True): logits from the 1x1 head at 1/8 resolution, decoder idle."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.loss import CrossEntropyLoss2d
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    g = load("g7_encoder_only.npz")
+    sd = O.synthetic_state(O.erfnet_template(20))
+    x = S.synthetic_images(2, 64, 128, seed=77).to(DEV)
+    t = S.synthetic_labels(2, 8, 16, 20, seed=77).to(DEV)
+
+    def build():
+        m = E.ERFNet(20)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        for name, mod in m.named_modules():
+            if f"mask_{name}" in g.files:
+                mod.__dict__["_erf_forced_mask"] = torch.from_numpy(g[f"mask_{name}"])
+        return m
+
+    # plain autograd through the module API
+    ref_model = build()
+    y = ref_model(x, only_encode=True)
+    assert tuple(y.shape) == (2, 20, 8, 16)
+    loss_ref = CrossEntropyLoss2d(torch.tensor(O.CITYSCAPES_WEIGHTS)).to(DEV)(y, t[:, 0])
+    loss_ref.backward()
+    gold = float(g["loss"])
+    assert abs(loss_ref.item() - gold) <= 1e-4 * abs(gold), (loss_ref.item(), gold)
+    check_packed(g, "logits", y.detach().cpu(), 3e-4)
+    names = [str(s) for s in g["param_names"]]
+    gn = g["gradnorm"]
+    params = dict(ref_model.named_parameters())
+    for i, k in enumerate(names):
+        if gn[i] < 0:
+            assert k.startswith("decoder.") and params[k].grad is None
+            continue
+        mine = params[k].grad.double().norm().item()
+        if pre_bn_bias(k):
+            assert mine < 2e-3 and gn[i] < 2e-3
+            continue
+        assert abs(mine - gn[i]) <= 2e-2 * max(gn[i], 1e-6), (k, mine, gn[i])
+    for key in [f for f in g.files if f.startswith("grad_") and f.endswith("__shape")]:
+        k = key[len("grad_"):-len("__shape")]
+        check_packed(g, "grad_" + k, params[k].grad.cpu(), 3e-2, floor=30.0 if pre_bn_bias(k) else 0.0, outlier_frac=0.02, l2tol=5e-2)
+
+    # the trainer in encoder-only mode: same gradients in the arena, decoder untouched by Adam
+    model = build()
+    tr = Trainer(model, CITYSCAPES_WEIGHTS, only_encode=True)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    tr.zero_grad()
+    loss, out = tr.step(x, t)
+    assert loss.item() == loss_ref.item() and tuple(out.shape) == (2, 20, 8, 16)
+    mp = dict(model.named_parameters())
+    moved = g["moved"]
+    for i, k in enumerate(names):
+        o, n = tr.offsets[k]
+        if k.startswith("decoder."):
+            assert float(tr.gflat[o:o + n].abs().sum()) == 0.0 and torch.equal(mp[k].detach(), before[k]) and moved[i] == 0.0
+        else:
+            assert torch.equal(tr.gflat[o:o + n].view_as(params[k]), params[k].grad), k
+    ps = np.array([mp[k].detach().double().sum().item() for k in names])
+    n_el = np.array([mp[k].numel() for k in names])
+    flips = np.maximum(np.ceil(0.02 * n_el), 2)
+    keep = np.array([not pre_bn_bias(k) for k in names])
+    assert np.all((np.abs(ps - g["paramsum"]) <= 1e-5 * np.maximum(g["paramabs"], 1e-3) + flips * 2 * tr.lr)[keep])
+    hw = "encoder.output_conv.weight"
+    p0, gk = before[hw].cpu(), params[hw].grad.cpu()
+    m0, v0 = torch.zeros_like(p0), torch.zeros_like(p0)
+    O.adam_step([p0], [gk], [m0], [v0], 1, lr=tr.lr)
+    assert rel_err(mp[hw].detach().cpu(), p0) <= 1e-6
+
+
 def test_caches_follow_raw_pointer_parameter_updates():
     """The fused optimiser writes parameters through raw pointers (no torch version bump): eval-mode caches of
     packed weights / folded BatchNorm and the trainer's packed-weight bank must still see the new values."""

@@ -206,6 +206,51 @@ def test_g5_three_train_steps():
     check_packed(g, "final_exp_avg_sq_first", v[0], 0.2)
 
 
+def test_g7_encoder_only_stage():
+    """Oracle vs the reference run with only_encode=True (train/main.py:203): loss, logits, gradients, one Adam step."""
+    g = load("g7_encoder_only.npz")
+    for nc in (20, 6):
+        tag = f"head_{nc}"
+        seed = int(g[tag + "__seed"])
+        w = S.fill_tensor("encoder.output_conv.weight", (nc, 128, 1, 1), salt=seed).requires_grad_(True)
+        b = S.fill_tensor("encoder.output_conv.bias", (nc,), salt=seed).requires_grad_(True)
+        x = activations((2, 128, 9, 14), seed).requires_grad_(True)
+        y = torch.einsum("nchw,kc->nkhw", x, w[:, :, 0, 0]) + b.view(1, -1, 1, 1)
+        y.backward(upstream(tuple(y.shape), seed))
+        check_packed(g, tag + "_y", y, 1e-5)
+        check_packed(g, tag + "_dx", x.grad, 1e-5)
+        check_packed(g, tag + "_grad_weight", w.grad, 1e-5)
+        check_packed(g, tag + "_grad_bias", b.grad, 1e-5)
+    sd = O.synthetic_state(O.erfnet_template(20))
+    names = [str(s) for s in g["param_names"]]
+    wts = torch.tensor(O.CITYSCAPES_WEIGHTS, dtype=torch.float32)
+    x = S.synthetic_images(2, 64, 128, seed=77)
+    t = S.synthetic_labels(2, 8, 16, 20, seed=77)[:, 0]
+    masks = {str(k): torch.from_numpy(g[f"mask_{k}"]) for k in g["masks__keys"]}
+    loss, grads, new_running, _, logits = O.train_step_grads(sd, x, t, wts, masks, only_encode=True)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    check_packed(g, "logits", logits, 2e-5)
+    gn = g["gradnorm"]
+    for i, k in enumerate(names):
+        if gn[i] < 0:
+            assert k.startswith("decoder.") and grads[k] is None
+            continue
+        mine = grads[k].double().norm().item()
+        if pre_bn_bias(k):
+            assert mine < 1e-3 and gn[i] < 1e-3
+            continue
+        assert abs(mine - gn[i]) <= 2e-4 * max(gn[i], 1e-6), (k, mine, gn[i])
+    for key in [f for f in g.files if f.startswith("grad_") and f.endswith("__shape")]:
+        k = key[len("grad_"):-len("__shape")]
+        check_packed(g, "grad_" + k, grads[k], 1e-4)
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    O.adam_step([sd[k] for k in names], [grads[k] for k in names], m, v, 1, lr=5e-4)
+    ps = np.array([sd[k].double().sum().item() for k in names])
+    keep = np.array([not pre_bn_bias(k) for k in names])
+    assert np.all((np.abs(ps - g["paramsum"]) <= 2e-5 * np.maximum(g["paramabs"], 1e-3))[keep])
+
+
 def test_g6_imagenet_encoder_classifier():
     g = load("g6_imagenet.npz")
     sd = O.synthetic_state(O.imagenet_template(1000))
