@@ -93,27 +93,31 @@ size_t bn_workspace_bytes(int C) { return (size_t)RED_MAX_GROUPS * 2 * C * sizeo
 float* bn_workspace_coef(void* workspace, int C) { return (float*)((double*)workspace + (size_t)RED_MAX_GROUPS * 2 * C); }
 
 
-// Sum the fp64 partials [groups][2C] per channel with all 1024 threads of the block: thread
-// (part, c) adds groups part, part + nparts, ...; the parts meet in LDS.  On return threads
-// tid < C hold the two column sums of channel tid.
-#define FIN_THREADS 1024
+// Sum the fp64 partials [groups][2C] per channel.  One block owns FIN_CB consecutive channels (a single block
+// for all channels is limited by what one CU can pull from memory); thread (part, cl) adds groups part,
+// part + FIN_PARTS, ... of channel c0 + cl, the parts meet in LDS in a fixed order.  On return threads
+// tid < FIN_CB hold the two column sums of channel blockIdx.x * FIN_CB + tid (when that is < C).
+#define FIN_THREADS 256
+#define FIN_CB 8
+#define FIN_PARTS (FIN_THREADS / FIN_CB)
+static inline int fin_blocks(int C) { return (C + FIN_CB - 1) / FIN_CB; }
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int groups, int C, double& s, double& ss) {
     __shared__ double sh[2 * FIN_THREADS];
-    const int nparts = FIN_THREADS / C;
-    const int c = threadIdx.x % C, part = threadIdx.x / C;
+    const int cl = threadIdx.x % FIN_CB, part = threadIdx.x / FIN_CB;
+    const int c = blockIdx.x * FIN_CB + cl;
     double a = 0, b = 0;
-    if (part < nparts) {
+    if (c < C) {
         // eight independent chains keep the loads in flight; the order of the additions is fixed
         double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int g = part;
-        for (; g + 7 * nparts < groups; g += 8 * nparts) {
+        for (; g + 7 * FIN_PARTS < groups; g += 8 * FIN_PARTS) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                a8[u] += partials[(long long)(g + u * nparts) * 2 * C + c];
-                b8[u] += partials[(long long)(g + u * nparts) * 2 * C + C + c];
+                a8[u] += partials[(long long)(g + u * FIN_PARTS) * 2 * C + c];
+                b8[u] += partials[(long long)(g + u * FIN_PARTS) * 2 * C + C + c];
             }
         }
-        for (; g < groups; g += nparts) {
+        for (; g < groups; g += FIN_PARTS) {
             a8[0] += partials[(long long)g * 2 * C + c];
             b8[0] += partials[(long long)g * 2 * C + C + c];
         }
@@ -124,18 +128,19 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     sh[FIN_THREADS + threadIdx.x] = b;
     __syncthreads();
     s = 0; ss = 0;
-    if (threadIdx.x < C)
-        for (int k = 0; k < nparts; ++k) { s += sh[k * C + threadIdx.x]; ss += sh[FIN_THREADS + k * C + threadIdx.x]; }
+    if (threadIdx.x < FIN_CB)
+        for (int k = 0; k < FIN_PARTS; ++k) { s += sh[k * FIN_CB + threadIdx.x]; ss += sh[FIN_THREADS + k * FIN_CB + threadIdx.x]; }
 }
 
 __global__ void channel_sum_finalize_kernel(const double* __restrict__ partials, int groups, int C, float* __restrict__ sums) {
     double s, ss;
     reduce_partials(partials, groups, C, s, ss);
-    if (threadIdx.x < C) sums[threadIdx.x] = (float)s;
+    const int c = blockIdx.x * FIN_CB + threadIdx.x;
+    if (threadIdx.x < FIN_CB && c < C) sums[c] = (float)s;
 }
 
 int channel_sum_finalize_launch(const float* partials, int groups, int C, float* sums, hipStream_t stream) {
-    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, sums);
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(fin_blocks(C)), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, sums);
     return erf_check_launch();
 }
 
@@ -164,8 +169,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partials, int grou
                                    float* __restrict__ scale, float* __restrict__ shift) {
     double s, ss;
     reduce_partials(partials, groups, C, s, ss);
-    if (threadIdx.x < C) {
-        const int c = threadIdx.x;
+    const int c = blockIdx.x * FIN_CB + threadIdx.x;
+    if (threadIdx.x < FIN_CB && c < C) {
         const double m = s / count;
         double var = ss / count - m * m;
         if (var < 0) var = 0;
@@ -186,7 +191,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partials, int grou
 int bn_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                        float* scale, float* shift, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, (double)count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(fin_blocks(C)), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, (double)count, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return erf_check_launch();
 }
@@ -268,8 +273,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int 
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
     double s, sx;
     reduce_partials(partials, groups, C, s, sx);
-    if (threadIdx.x < C) {
-        const int c = threadIdx.x;
+    const int c = blockIdx.x * FIN_CB + threadIdx.x;
+    if (threadIdx.x < FIN_CB && c < C) {
         dbeta[c] = (float)s;
         dgamma[c] = (float)sx;
         coef[c] = gamma[c] * invstd[c];
@@ -280,7 +285,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int 
 
 int bn_bwd_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma,
                            const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* coef, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, (double)count, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(fin_blocks(C)), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, (double)count, gamma,
                        invstd, batch_stats, dgamma, dbeta, coef);
     return erf_check_launch();
 }
