@@ -133,7 +133,7 @@ def channel_sum(z, out=None):
     return out
 
 
-def pre_bn_bias_grad(dz, batch_stats, out=None):
+def pre_bn_bias_grad(dz, batch_stats, out=None, out_is_zero=False):
     """Gradient of a conv bias that feeds a BatchNorm directly.  With batch statistics the BatchNorm backward
     removes the per-channel mean of its output gradient, so sum_p dz[p][c] is exactly zero in exact arithmetic
     (the reference computes rounding noise around zero): write the analytic value and skip the pass over dz.
@@ -143,7 +143,7 @@ def pre_bn_bias_grad(dz, batch_stats, out=None):
     c = dz.shape[-1]
     if out is None:
         return torch.zeros(c, device=dz.device)
-    return out.zero_()
+    return out if out_is_zero else out.zero_()
 
 
 def conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation):
@@ -183,6 +183,8 @@ class _Sink:
 
     def __init__(self, mod):
         self.views = mod.__dict__.get("_erf_grad_sink") if mod is not None else None
+        # the owner of the arena clears it before every backward pass: analytic zeros need no fill of their own
+        self.zeroed = self.views is not None and bool(mod.__dict__.get("_erf_grad_sink_zeroed"))
         self.after = mod.__dict__.get("_erf_after_backward") if mod is not None else None
 
     def out(self, name, shape, dev):
@@ -235,7 +237,7 @@ class _NB1dFn(torch.autograd.Function):
         o = lambda name, shape: sk.out(name, shape, dev)
         dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True,
                                             dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
-        db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)))
+        db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)), sk.zeroed)
         dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
         dz3, db3 = conv1d_dgrad_bias(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d,
                                      o("conv3x1_2.bias", (c,)))
@@ -243,7 +245,7 @@ class _NB1dFn(torch.autograd.Function):
         da2 = conv1d_dgrad(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), None, None, AXIS_H, d)
         dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
                                         dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
-        db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)))
+        db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)), sk.zeroed)
         dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
         dz1, db1 = conv1d_dgrad_bias(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1,
                                      o("conv3x1_1.bias", (c,)))
@@ -287,7 +289,8 @@ class _DownFn(torch.autograd.Function):
                                            dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
         db = sk.out("conv.bias", (cc,), dev)
         if ctx.training:
-            db.zero_()                                   # analytic value, see pre_bn_bias_grad
+            if not sk.zeroed:
+                db.zero_()                               # analytic value, see pre_bn_bias_grad
         else:
             db.copy_(channel_sum(dz)[:cc])
         dw = sk.out("conv.weight", w.shape, dev)
@@ -341,7 +344,7 @@ class _UpFn(torch.autograd.Function):
         sk = _Sink(ctx.mod)
         dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
                                            dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
-        db = pre_bn_bias_grad(dz, ctx.training, sk.out("conv.bias", (cout,), dev))
+        db = pre_bn_bias_grad(dz, ctx.training, sk.out("conv.bias", (cout,), dev), sk.zeroed)
         dw = sk.out("conv.weight", w.shape, dev)
         nb = query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)
         ws = _ws(nb, dev)

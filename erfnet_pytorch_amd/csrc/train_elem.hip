@@ -606,34 +606,56 @@ int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, dou
 // the position inside the 2x2 output patch; channels >= 4*nc zero), the layout output_conv's
 // backward GEMMs take.  `ncp` = ld / 4.
 // S = 1 is the degenerate patch: channel = class (Encoder.output_conv, the 1x1 head).
+template <typename TS> __device__ __forceinline__ void ld_pair(const TS* p, float& a, float& b);
+template <> __device__ __forceinline__ void ld_pair<float>(const float* p, float& a, float& b) {
+    const f32x2 v = *(const f32x2*)p;
+    a = v[0]; b = v[1];
+}
+template <> __device__ __forceinline__ void ld_pair<bf16raw>(const bf16raw* p, float& a, float& b) {
+    const uint32_t v = *(const uint32_t*)p;
+    a = __builtin_bit_cast(float, v << 16); b = __builtin_bit_cast(float, v & 0xFFFF0000u);
+}
+
 template <typename TS, typename T, int S>
 __global__ __launch_bounds__(256) void patches_kernel(const TS* __restrict__ dl, T* __restrict__ out, int N, int H, int W,
                                                       int nc, int ncp, int ld) {
-    // one block = 64 consecutive input pixels of one image row-major range; tile[px][v] in LDS
+    // one block = 64 consecutive pixels of the [N,H,W] grid; tile[px][v] in LDS (odd pitch: the transposing
+    // accesses below hit distinct banks)
     extern __shared__ float tile[];                 // [64][ld + 1]
     const long long P = (long long)N * H * W;
     const long long pix0 = (long long)blockIdx.x * 64;
     const int ldt = ld + 1;
-    // read: lanes run over the 64 pixels (stride-2 floats inside a plane row), v over the warps
-    for (int id = threadIdx.x; id < 64 * ld; id += 256) {
-        const int px = id & 63, v = id >> 6;
-        const long long pix = pix0 + px;
-        float val = 0.f;
-        const int cls = S == 2 ? v >> 2 : v, ph = S == 2 ? v & 3 : 0;
-        if (pix < P && cls < nc) {
-            const int j = (int)(pix % W);
-            const long long rest = pix / W;
-            const int i = (int)(rest % H);
-            const int n = (int)(rest / H);
-            val = Elem<TS>::ld(dl + (((long long)n * nc + cls) * (S * H) + S * i + (ph >> 1)) * (S * W) + S * j + (ph & 1));
+    // read: a thread keeps its pixel (lane -> consecutive columns: full-line reads of the planes) and walks over
+    // (class, patch row); both columns of the patch row come with one 8-byte load
+    const int px = threadIdx.x & 63;
+    const long long pix = pix0 + px;
+    const bool live = pix < P;
+    const int j = (int)(pix % W);
+    const long long rest = pix / W;
+    const int i = (int)(rest % H);
+    const long long n = rest / H;
+    const long long plane = (long long)(S * H) * (S * W);
+    const TS* src = dl + n * nc * plane + (long long)(S * i) * (S * W) + S * j;
+    const int items = ld / S;                       // (class, patch row) pairs incl. the zero padding
+    for (int it = threadIdx.x >> 6; it < items; it += 4) {
+        const int cls = S == 2 ? it >> 1 : it, a = S == 2 ? it & 1 : 0;
+        float v0 = 0.f, v1 = 0.f;
+        if (live && cls < nc) {
+            if (S == 2) ld_pair<TS>(src + cls * plane + (long long)a * (S * W), v0, v1);
+            else v0 = Elem<TS>::ld(src + cls * plane);
         }
-        tile[px * ldt + v] = val;
+        tile[px * ldt + it * S] = v0;
+        if (S == 2) tile[px * ldt + it * S + 1] = v1;
     }
     __syncthreads();
-    // write: the 64 pixels x ld channels are one contiguous run of the NHWC tensor
-    for (int id = threadIdx.x; id < 64 * ld; id += 256) {
-        const int px = id / ld, v = id % ld;
-        if (pix0 + px < P) Elem<T>::st(out + (pix0 + px) * ld + v, tile[px * ldt + v]);
+    // write: the 64 pixels x ld channels are one contiguous run of the NHWC tensor; 4 channels per thread
+    const int ld4 = ld >> 2;
+    for (int id = threadIdx.x; id < 64 * ld4; id += 256) {
+        const int p4 = id / ld4, v = (id % ld4) * 4;
+        if (pix0 + p4 < P) {
+            const float* t = tile + p4 * ldt + v;
+            store4<T>(out + (pix0 + p4) * ld + v, f32x4{t[0], t[1], t[2], t[3]});
+        }
     }
 }
 

@@ -98,6 +98,7 @@ class Trainer:
                 o, n = self.offsets[f"{mname}.{k}"]
                 views[k] = self.gflat[o:o + n].view_as(prm)
             mod.__dict__["_erf_grad_sink"] = views
+            mod.__dict__["_erf_grad_sink_zeroed"] = True    # step() clears the arena before every backward pass
 
         self._bank = None                               # packed factorized-conv weights, refreshed once per step
         # all-reduce buckets (backward-completion order) and the ranges Adam may touch
@@ -137,6 +138,7 @@ class Trainer:
         """images [N,3,H,W]; targets [N,1,H,W] or [N,H,W] int64.  Returns the (global) loss tensor."""
         if targets.dim() == 4:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
+        self.zero_grad()                                              # optimizer.zero_grad(), train/main.py:200
         self._refresh_packed(images)
         outputs = self.model(images, only_encode=True) if self.only_encode else self.model(images)
         loss = weighted_cross_entropy(outputs, targets, self.weight, self.group if self.world > 1 else None)
@@ -195,6 +197,7 @@ class ArenaSGD:
                 views[k] = self.gflat[o:o + n].view_as(prm)
                 sunk.add(f"{mname}.{k}")
             mod.__dict__["_erf_grad_sink"] = views
+            mod.__dict__["_erf_grad_sink_zeroed"] = True    # step() clears the arena before every backward pass
         self._views = [(p, self.gflat[o:o + n].view_as(p)) for (name, p), (o, n) in
                        ((np_, self.offsets[np_[0]]) for np_ in named) if name not in sunk]
 
@@ -241,8 +244,7 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     t[torch.rand(t.shape, device=dev, generator=gen) < 0.05] = 19
 
     def step():
-        tr.zero_grad()
-        return tr.step(x, t)
+        return tr.step(x, t)                  # zero_grad + forward + loss + backward + all-reduce + Adam
 
     for _ in range(max(args.warmup, 1)):
         loss, _ = step()
