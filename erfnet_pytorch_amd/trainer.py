@@ -150,6 +150,54 @@ class Trainer:
     def _refresh_packed(self, images):
         self._bank = _refresh_bank(self._bank, self.model, images)
 
+    # -- checkpoint / resume (train/main.py:143-153 loads, :320-326 saves 'optimizer': optimizer.state_dict()) --------
+    def _is_active(self, name):
+        o, _ = self.offsets[name]
+        return any(lo <= o < hi for lo, hi in self.active)
+
+    def optimizer_state_dict(self):
+        """The arena's Adam state in torch.optim.Adam.state_dict() form (parameter index = registration order), so a
+        checkpoint written here resumes under the reference's optimiser and vice versa.  Parameters that never took
+        part in a step carry no state, exactly like torch's lazily created per-parameter state."""
+        names = [k for k, _ in self.model.named_parameters()]
+        params = dict(self.model.named_parameters())
+        state = {}
+        if self.step_count > 0:
+            for i, k in enumerate(names):
+                if not self._is_active(k):
+                    continue
+                o, n = self.offsets[k]
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[o:o + n].view_as(params[k]).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(params[k]).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        names = [k for k, _ in self.model.named_parameters()]
+        group = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or list(group["params"]) != list(range(len(names))):
+            raise ValueError("optimizer state does not describe this model's parameter list")
+        if group.get("amsgrad") or group.get("maximize"):
+            raise ValueError("amsgrad / maximize are not part of the reference recipe and are not supported")
+        self.lr, self.betas, self.eps, self.wd = group["lr"], tuple(group["betas"]), group["eps"], group["weight_decay"]
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, st in sd["state"].items():
+            k = names[int(i)]
+            if not self._is_active(k):
+                raise ValueError(f"optimizer state for {k}, which this training stage does not update")
+            o, n = self.offsets[k]
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the arena keeps one step counter")
+        self.step_count = steps.pop() if steps else 0
+
     def optimizer_step(self):
         from . import ops
         ops.bump_param_epoch()                          # parameters change below through raw pointers

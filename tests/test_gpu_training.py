@@ -476,6 +476,54 @@ def test_encoder_only_train_step_vs_golden():
     assert rel_err(mp[hw].detach().cpu(), p0) <= 1e-6
 
 
+def test_trainer_checkpoint_resume_is_interchangeable_with_torch_adam():
+    """'optimizer': optimizer.state_dict() of train/main.py:320-326 / :149-152: the arena's Adam state leaves and enters in
+    torch.optim.Adam's own format; resuming from it continues bit-identically, and torch's Adam resumed from it agrees."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    sd0 = O.synthetic_state(O.erfnet_template(20))
+    x = S.synthetic_images(2, 64, 128, seed=91).to(DEV)
+    t = S.synthetic_labels(2, 64, 128, 20, seed=91).to(DEV)
+
+    def build(state):
+        m = E.ERFNet(20)
+        m.load_state_dict(state)
+        m = m.to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
+                mod.__dict__["_erf_forced_mask"] = torch.ones(2, mod.conv3x1_1.out_channels)      # dropout off: deterministic
+        return m
+
+    a = build(sd0)
+    tra = Trainer(a, CITYSCAPES_WEIGHTS)
+    tra.step(x, t)
+    ckpt = {"state_dict": {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}, "optimizer": tra.optimizer_state_dict()}
+    n_params = len(list(a.named_parameters()))
+    assert len(ckpt["optimizer"]["state"]) == n_params - 2               # encoder.output_conv.{weight,bias} never stepped
+    # (1) resume in a fresh Trainer: second step identical to continuing
+    b = build(ckpt["state_dict"])
+    trb = Trainer(b, CITYSCAPES_WEIGHTS)
+    trb.load_optimizer_state_dict(ckpt["optimizer"])
+    assert trb.step_count == 1
+    tra.step(x, t)
+    trb.step(x, t)
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), k
+    # (2) the reference's optimiser accepts the same dict and takes the same second step from the same gradients
+    c = build(ckpt["state_dict"])
+    opt = torch.optim.Adam(c.parameters(), 5e-4, (0.9, 0.999), eps=1e-08, weight_decay=1e-4)
+    opt.load_state_dict(ckpt["optimizer"])
+    for (k, p) in c.named_parameters():
+        o, n = trb.offsets[k]
+        p.grad = trb.gflat[o:o + n].view_as(p).clone() if trb._is_active(k) else None
+    opt.step()
+    for (k, p), (_, q) in zip(c.named_parameters(), b.named_parameters()):
+        assert rel_err(p.detach().cpu(), q.detach().cpu()) <= 1e-6, k
+    # and torch's state after that step loads back
+    trb.load_optimizer_state_dict(opt.state_dict())
+    assert trb.step_count == 2
+
+
 def test_caches_follow_raw_pointer_parameter_updates():
     """The fused optimiser writes parameters through raw pointers (no torch version bump): eval-mode caches of
     packed weights / folded BatchNorm and the trainer's packed-weight bank must still see the new values."""
