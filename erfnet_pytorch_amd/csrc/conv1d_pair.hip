@@ -121,8 +121,13 @@ struct ImmMid {
 // One GEMM of the pair: acc[pt][c] += W[c][ks] x B(pt, ks); B fragments come from LDS at
 // lb[class] + immediate through hand-placed reads in groups of GS, group g+1 in flight while group g
 // feeds the MFMAs (LDS reads return in order, so "at most GS outstanding" means group g has arrived).
-template <int C, int TC, int PTW, int CTW, typename IMM>
-__device__ __forceinline__ void mfma_phase(const int* lb, const i32x4 (&wreg)[CTW][(3 * (C / 8) + 3) / 4], f32x4 (&acc)[PTW][CTW], int q) {
+//
+// `epi(pt)` consumes the accumulators of pixel tile pt.  It is called for the tiles finished by group g - 1 right
+// after group g's matrix instructions are issued, so its VALU / LDS-write work runs under those instructions
+// instead of after the whole phase; the tiles finished by the last group follow the loop.
+template <int C, int TC, int PTW, int CTW, typename IMM, typename EPI>
+__device__ __forceinline__ void mfma_phase(const int* lb, const i32x4 (&wreg)[CTW][(3 * (C / 8) + 3) / 4], f32x4 (&acc)[PTW][CTW], int q,
+                                           EPI&& epi) {
     constexpr int CH = C / 8;
     constexpr int PIXB = C * 2;
     constexpr int KS = (3 * CH + 3) / 4;
@@ -165,7 +170,11 @@ __device__ __forceinline__ void mfma_phase(const int* lb, const i32x4 (&wreg)[CT
             for (int c = 0; c < CTW; ++c)            // the first K-step starts from a literal zero: no accumulator clearing
                 acc[pt][c] = mma_step<T>(wreg[c][ks], b, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pt][c]);
         });
+        constexpr int done_lo = g == 0 ? 0 : ((g - 1) * GS) / KS;       // tiles complete before group g - 1 started
+        constexpr int done_hi = (g * GS) / KS;                           // ... before this group started
+        static_for<done_lo, done_hi>([&](auto pt) { epi(pt); });
     });
+    static_for<((NG - 1) * GS) / KS, PTW>([&](auto pt) { epi(pt); });
 }
 
 
@@ -332,13 +341,10 @@ void conv1d_pair_kernel(const PairParams p) {
             for (int pt = 0; pt < PTW; ++pt)
 #pragma unroll
                 for (int c = 0; c < CTW; ++c) acc[pt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            mfma_phase<C, TC, PTW, CTW, ImmIn>(lb, wA, acc, q);
         }
-
-        // ---------------- intermediate = relu(sA * acc + tA) -> LDS rows (zero right of the image)
-#pragma unroll
-        for (int pt = 0; pt < PTW; ++pt) {
+        // intermediate = relu(sA * acc + tA) -> LDS rows (zero right of the image)
+        auto ep1 = [&](auto pti) {
+            constexpr int pt = decltype(pti)::value;
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
                 f32x4 v = acc[pt][c];
@@ -346,7 +352,9 @@ void conv1d_pair_kernel(const PairParams p) {
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sA[c][e] + tA[c][e], 0.f);
                 *(i32x2*)(smem + mid_w[c] + ((pt / TB) * RS + (pt % TB) * 16) * PIXB) = pack_bf16x4(v);
             }
-        }
+        };
+        if (p.dbg & 4) static_for<0, PTW>(ep1);
+        else mfma_phase<C, TC, PTW, CTW, ImmIn>(lb, wA, acc, q, ep1);
         if (g.jhi < TC) {                             // wave-uniform and rare: tiles at the right image edge
 #pragma unroll
             for (int pt = 0; pt < PTW; ++pt) {
@@ -359,11 +367,9 @@ void conv1d_pair_kernel(const PairParams p) {
         ERF_LDS_BARRIER();                 // intermediate complete; input tile no longer read
 
         // ---------------- GEMM 2: 1x3 over the intermediate rows
-        if (!(p.dbg & 4)) mfma_phase<C, TC, PTW, CTW, ImmMid>(lb2, wB, acc, q);
-
-        // ---------------- accumulators -> LDS as [pixel][C] bf16 (in the consumed input buffer)
-#pragma unroll
-        for (int pt = 0; pt < PTW; ++pt) {
+        // accumulators -> LDS as [pixel][C] bf16 (in the consumed input buffer)
+        auto ep2 = [&](auto pti) {
+            constexpr int pt = decltype(pti)::value;
 #pragma unroll
             for (int c = 0; c < CTW; ++c) {
                 f32x4 v = acc[pt][c];
@@ -374,7 +380,9 @@ void conv1d_pair_kernel(const PairParams p) {
                 }
                 *(i32x2*)(smem + boff + stg_w[c] + pt * 16 * PIXB) = pack_bf16x4(v);
             }
-        }
+        };
+        if (p.dbg & 4) static_for<0, PTW>(ep2);
+        else mfma_phase<C, TC, PTW, CTW, ImmMid>(lb2, wB, acc, q, ep2);
         ERF_LDS_BARRIER();                 // staging complete; intermediate no longer read
 
         // ---------------- coalesced read-back (+ residual, ReLU)

@@ -19,7 +19,7 @@ __device__ __forceinline__ int swz(int pix, int chunk) {       // an involution:
     if constexpr (CH >= 16) {
         return ((chunk & 15) ^ (pix & 15)) | (chunk & ~15);
     } else {
-        constexpr int PPR = 16 / CH;
+        constexpr int PPR = CH >= 8 ? 1 : 8 / CH;      // LDS serves 128 bytes a cycle: 8 consecutive pixels must hit 8 distinct 16-byte slots
         return chunk ^ ((pix / PPR) & (CH - 1));
     }
 }
