@@ -9,6 +9,8 @@ the parameters' own torch layouts whatever the activation dtype (fp32 or bf16).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -100,6 +102,65 @@ def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=No
         raise RuntimeError(f"erf_conv1d_dgrad_bias failed with status {rc}")
     dx = conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation)
     return dx, channel_sum(dx, db)
+
+
+# ---- BatchNorm backward riding on the data-gradient convolution that produces its incoming gradient -------------------
+# A block's last BatchNorm (bn2 of non_bottleneck_1d, bn of the samplers) receives its gradient from the block that
+# follows.  When that block is a non_bottleneck_1d, its final data-gradient convolution applies the producer's ReLU gate
+# and takes the producer's two BatchNorm-backward sums in its epilogue; the producer's backward then finds dz / dgamma /
+# dbeta ready.  Forward: the producer hangs a BnTail on the tensor it returns; the consumer keeps it for its backward.
+# Backward: the consumer leaves a one-slot hand-off that the very next block backward takes (or discards).
+FUSE_BN_BACKWARD = os.environ.get("ERF_FUSE_BN_BACKWARD", "1") != "0"
+FUSED_BN_BACKWARD_CALLS = [0]             # diagnostic counter (tests check that the fused path is the one that runs)
+_HANDOFF = [None]
+
+
+class BnTail:
+    __slots__ = ("mod", "prefix", "out_ptr", "z", "mean", "invstd", "gamma", "mask", "training")
+
+    def __init__(self, mod, prefix, out, z, mean, invstd, gamma, mask, training):
+        self.mod, self.prefix, self.out_ptr = mod, prefix, out.data_ptr()
+        self.z, self.mean, self.invstd, self.gamma, self.mask, self.training = z, mean, invstd, gamma, mask, training
+
+
+def _with_tail(out, tail):
+    y = ops.to_nchw_view(out)
+    if FUSE_BN_BACKWARD:
+        y._erf_bn_tail = tail
+    return y
+
+
+def _tail_of(x, xh):
+    t = getattr(x, "_erf_bn_tail", None) if FUSE_BN_BACKWARD else None
+    return t if t is not None and t.out_ptr == xh.data_ptr() and t.z.shape == xh.shape and t.z.dtype == xh.dtype else None
+
+
+def _take_handoff(g):
+    h, _HANDOFF[0] = _HANDOFF[0], None
+    if h is not None and h[0] == g.data_ptr() and h[1] == tuple(g.shape):
+        return h[2]
+    return None
+
+
+def conv1d_dgrad_bn_backward(dy, packed_t, gate, residual, axis, dilation, z, mean, invstd, gamma, mask, batch_stats,
+                             dgamma=None, dbeta=None):
+    """dx = [gate > 0] * (conv1d_dgrad(dy) + residual), then the backward of the BatchNorm (z, mean, invstd, gamma, mask)
+    whose output gradient dx is.  Returns (dx, dz, dgamma, dbeta), or None when the fused kernel does not take the shape."""
+    n, h, w, c = dy.shape
+    dev = dy.device
+    dx, dz = torch.empty_like(dy), torch.empty_like(z)
+    dgamma = torch.empty(c, device=dev) if dgamma is None else dgamma
+    dbeta = torch.empty(c, device=dev) if dbeta is None else dbeta
+    ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+    rc = query("erf_conv1d_dgrad_bn_backward", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), gate.data_ptr(), _p(residual),
+               ops.dt(dy), n, h, w, c, axis, dilation, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+               _p(mask), int(batch_stats), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream())
+    if rc == 0:
+        FUSED_BN_BACKWARD_CALLS[0] += 1
+        return dx, dz, dgamma, dbeta
+    if rc != -2:
+        raise RuntimeError(f"erf_conv1d_dgrad_bn_backward failed with status {rc}")
+    return None
 
 
 def bn_apply(z, center, scale, shift, residual=None, mask=None, relu=True):
@@ -226,7 +287,8 @@ class _NB1dFn(torch.autograd.Function):
         out = bn_apply(z4, mean2, s2, t2, residual=xh, mask=mask)
         ctx.save_for_backward(xh, a1, z2, a2, a3, z4, out, mean1, invstd1, mean2, invstd2, w1, w2, w3, w4, g1, g2)
         ctx.mask, ctx.d, ctx.training, ctx.mod = mask, d, training, mod
-        return ops.to_nchw_view(out)
+        ctx.tail = _tail_of(x, xh)
+        return _with_tail(out, BnTail(mod, "bn2", out, z4, mean2, invstd2, g2, mask, training))
 
     @staticmethod
     def backward(ctx, gout):
@@ -235,22 +297,43 @@ class _NB1dFn(torch.autograd.Function):
         g = _grad_nhwc(gout, xh)
         sk, dev, c = _Sink(ctx.mod), xh.device, xh.shape[3]
         o = lambda name, shape: sk.out(name, shape, dev)
-        dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True,
-                                            dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
+        ready = _take_handoff(g)
+        if ready is not None:                 # the block after this one gated g and ran this bn2's backward already
+            dz4, dg2, dbe2 = ready
+            g_res = g
+        else:
+            dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True,
+                                                dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
         db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)), sk.zeroed)
         dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
         dz3, db3 = conv1d_dgrad_bias(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d,
                                      o("conv3x1_2.bias", (c,)))
         dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape))
-        da2 = conv1d_dgrad(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), None, None, AXIS_H, d)
-        dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
-                                        dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
+        fused = conv1d_dgrad_bn_backward(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), a2, None, AXIS_H, d, z2,
+                                         mean1, invstd1, _f32(g1), None, ctx.training, o("bn1.weight", (c,)),
+                                         o("bn1.bias", (c,))) if FUSE_BN_BACKWARD else None
+        if fused is not None:
+            _, dz2, dg1, dbe1 = fused
+        else:
+            da2 = conv1d_dgrad(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), None, None, AXIS_H, d)
+            dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
+                                            dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
         db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)), sk.zeroed)
         dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
         dz1, db1 = conv1d_dgrad_bias(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1,
                                      o("conv3x1_1.bias", (c,)))
         dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape))
-        dx = conv1d_dgrad(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), None, g_res, AXIS_H, 1)
+        t, fused = ctx.tail, None
+        if t is not None:                     # this block's input is the ReLU output of a BatchNorm: run that layer's backward here
+            psk = _Sink(t.mod)
+            fused = conv1d_dgrad_bn_backward(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), xh, g_res, AXIS_H, 1, t.z,
+                                             t.mean, t.invstd, _f32(t.gamma), t.mask, t.training,
+                                             psk.out(t.prefix + ".weight", (c,), dev), psk.out(t.prefix + ".bias", (c,), dev))
+        if fused is not None:
+            dx = fused[0]
+            _HANDOFF[0] = (dx.data_ptr(), tuple(dx.shape), fused[1:])
+        else:
+            dx = conv1d_dgrad(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), None, g_res, AXIS_H, 1)
         return (ops.to_nchw_view(dx), None) + sk.ret(dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)
 
 
@@ -275,7 +358,7 @@ class _DownFn(torch.autograd.Function):
         ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
         ctx.cin, ctx.cout, ctx.training, ctx.code, ctx.mod = cin, cout, mod.training, code, mod
         ctx.need_dx = x.requires_grad
-        return ops.to_nchw_view(out)
+        return _with_tail(out, BnTail(mod, "bn", out, z, mean, invstd, gamma, None, mod.training))
 
     @staticmethod
     def backward(ctx, gout):
@@ -285,8 +368,12 @@ class _DownFn(torch.autograd.Function):
         dev = z.device
         g = _grad_nhwc(gout, z)
         sk = _Sink(ctx.mod)
-        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
-                                           dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
+        ready = _take_handoff(g)
+        if ready is not None:
+            dz, dgamma, dbeta = ready
+        else:
+            dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
+                                               dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
         db = sk.out("conv.bias", (cc,), dev)
         if ctx.training:
             if not sk.zeroed:
@@ -332,7 +419,7 @@ class _UpFn(torch.autograd.Function):
         out = bn_apply(z, mean, s, t)
         ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
         ctx.training, ctx.mod = mod.training, mod
-        return ops.to_nchw_view(out)
+        return _with_tail(out, BnTail(mod, "bn", out, z, mean, invstd, gamma, None, mod.training))
 
     @staticmethod
     def backward(ctx, gout):
@@ -342,8 +429,12 @@ class _UpFn(torch.autograd.Function):
         cout = z.shape[3]
         g = _grad_nhwc(gout, z)
         sk = _Sink(ctx.mod)
-        dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
-                                           dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
+        ready = _take_handoff(g)
+        if ready is not None:
+            dz, dgamma, dbeta = ready
+        else:
+            dz, _, dgamma, dbeta = bn_backward(g, out, None, z, mean, invstd, _f32(gamma), ctx.training,
+                                               dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
         db = pre_bn_bias_grad(dz, ctx.training, sk.out("conv.bias", (cout,), dev), sk.zeroed)
         dw = sk.out("conv.weight", w.shape, dev)
         nb = query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)

@@ -118,6 +118,30 @@ int erf_conv1d_dgrad_bias(const void* dy, void* dx, const void* packed_t, const 
     return channel_sum_finalize_launch((const float*)workspace, groups, C, dbias, (hipStream_t)stream);
 }
 
+// dx = gate(conv1d_dgrad(dy) + residual), then the backward pass of the BatchNorm whose output gradient dx is:
+// its two reductions ride in the convolution's epilogue, so only the apply pass reads dx again.
+int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual,
+                                 int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
+                                 const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
+                                 int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    if (!dy || !dx || !packed_t || !gate || !bn_z || !bn_mean || !bn_invstd || !bn_gamma || !dz || !dgamma || !dbeta ||
+        !workspace || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || dilation < 1)
+        return ERF_EINVAL;
+    if (C != 16 && C != 64 && C != 128) return ERF_EUNSUPPORTED;
+    Conv1dBnTail tail{bn_z, bn_mean, bn_invstd, bn_mask, 1};
+    int groups = 0;
+    int rc = conv1d_buf_launch(dy, dx, packed_t, nullptr, nullptr, residual, gate, (double*)workspace, &groups, dtype, N, H, W, C,
+                               axis, dilation, 0, (hipStream_t)stream, &tail);
+    if (rc) return rc;
+    const long long P = (long long)N * H * W;
+    float* coef = bn_workspace_coef(workspace, C);
+    rc = bn_bwd_finalize_launch((const float*)workspace, groups, C, P, bn_gamma, bn_invstd, batch_stats, dgamma, dbeta, coef,
+                                (hipStream_t)stream);
+    if (rc) return rc;
+    return bn_bwd_apply_launch(dx, nullptr, bn_mask, bn_z, bn_mean, bn_invstd, coef, dz, nullptr, dtype, P, C, (long long)H * W,
+                               (hipStream_t)stream);
+}
+
 int erf_dropout2d_mask(float* mask, int count, float p, unsigned long long seed, void* stream) {
     if (!mask) return ERF_EINVAL;
     return dropout_mask_launch(mask, count, p, seed, (hipStream_t)stream);

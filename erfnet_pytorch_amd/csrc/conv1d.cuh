@@ -12,9 +12,20 @@ int conv1d_pair_launch(const void* x, void* y, const void* packedA, const void* 
                        const float* scaleB, const float* shiftB, const void* residual, int dtype, int N, int H, int W, int C,
                        int dilation, int relu, hipStream_t stream);
 
+// The output y is the gradient arriving at the output of a BatchNorm layer (y is a data gradient): take that layer's
+// two backward sums in the epilogue.  z: the layer's pre-normalisation input (same shape and type as y), mean / invstd
+// [C], mask: Dropout2d multipliers [N][C] applied after the BatchNorm (or null).  gate_after: with both a gate and a
+// residual, y = gate(conv + residual) instead of gate(conv) + residual.
+struct Conv1dBnTail {
+    const void* z;
+    const float *mean, *invstd, *mask;
+    int gate_after;
+};
+
 // Same convolution on the DMA / buffer-addressed kernel (conv1d_buf.hip).  `stats` (optional): [groups][2C] fp64 partial
-// rows (per-channel sum and sum of squares of the stored output), *groups = rows written (<= conv1d_buf_max_groups()).
+// rows, *groups = rows written (<= conv1d_buf_max_groups()): per-channel (sum, sum of squares) of the stored output, or,
+// with `tail`, (sum y*m, sum y*m*xhat) -- the partial rows bn_bwd_finalize_launch takes.
 int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, const void* residual,
                       const void* gate, double* stats, int* groups, int dtype, int N, int H, int W, int C, int axis, int dilation,
-                      int relu, hipStream_t stream);
+                      int relu, hipStream_t stream, const Conv1dBnTail* tail = nullptr);
 int conv1d_buf_max_groups();

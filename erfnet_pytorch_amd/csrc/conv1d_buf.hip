@@ -30,7 +30,12 @@ struct BufParams {
     const float* shift;
     const void* res;
     const void* gate;
-    double* stats;          // [grid][2C] partial (sum, sum of squares) rows, or null
+    double* stats;          // [grid][2C] partial rows, or null: (sum, sum of squares) of y, or the two sums below
+    // BatchNorm-backward sums of y taken as the gradient at a BatchNorm's output (null bz: off):
+    //   row = (sum y*m, sum y*m*xhat), xhat = (bz - bmean) * binvstd, m = bmask[image][channel] (null: 1)
+    const void* bz;
+    const float *bmean, *binvstd, *bmask;
+    int gate_after;         // gate and residual both given: 0: y = gate(conv) + res, 1: y = gate(conv + res)
     int d, relu;
     int A, Bn;
     long long img_stride;
@@ -44,6 +49,7 @@ struct BufParams {
 struct BufGeo {
     uint32_t soff;
     int ulo, uhi, vhi;
+    int img;                // image index of the tile (axis H), 0 when rows of all images are merged (axis W)
 };
 
 template <int PIXB>
@@ -68,10 +74,12 @@ __device__ __forceinline__ BufGeo buf_geo(const BufParams& p, int tile, int tile
     g.uhi = uhi > g.ulo ? uhi : g.ulo;
     const int vhi = p.Bn - b0;
     g.vhi = vhi < p.Tn ? vhi : p.Tn;
+    g.img = img;
     return g;
 }
 
-template <typename T, int C, int WM, int WN, int M, int KI, int OCC, bool POST, bool STATS>
+// STATS: 0 none, 1 (sum, sum of squares) of the output, 2 BatchNorm-backward sums of the output
+template <typename T, int C, int WM, int WN, int M, int KI, int OCC, bool POST, int STATS>
 __global__ __launch_bounds__(WM * WN * 64, OCC)
 void conv1d_buf_kernel(const BufParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -107,6 +115,7 @@ void conv1d_buf_kernel(const BufParams p) {
     const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y, p.bytes);
     const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.res ? p.res : p.x, p.bytes);
     const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.gate ? p.gate : p.x, p.bytes);
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(p.bz ? p.bz : p.x, p.bytes);
 
     i32x4 wreg[CTW][KS];
     f32x4 sc[CTW], sh[CTW];
@@ -197,6 +206,14 @@ void conv1d_buf_kernel(const BufParams p) {
     float ssum[EPC], ssq[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    float bmu[EPC], bis[EPC];            // STATS == 2: statistics of this thread's channel chunk (tid % CH)
+    if constexpr (STATS == 2) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            bmu[e] = p.bmean[(tid % CH) * EPC + e];
+            bis[e] = p.binvstd[(tid % CH) * EPC + e];
+        }
+    }
     const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
 
     int tile = blockIdx.x, tile_end = p.ntiles, G = gridDim.x;
@@ -319,12 +336,19 @@ void conv1d_buf_kernel(const BufParams p) {
                 ChunkOps<T>::unpack(outv[s], f);
                 ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, pv[s]), t);
                 if (p.gate) {
+                    if (both && p.gate_after) {
+                        float r[EPC];
+                        ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ooff[s], g.soff, 0)), r);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) f[e] = t[e] > 0.f ? f[e] : 0.f;
-                    if (both) {
-                        ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ooff[s], g.soff, 0)), t);
+                        for (int e = 0; e < EPC; ++e) f[e] = t[e] > 0.f ? f[e] + r[e] : 0.f;
+                    } else {
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) f[e] += t[e];
+                        for (int e = 0; e < EPC; ++e) f[e] = t[e] > 0.f ? f[e] : 0.f;
+                        if (both) {
+                            ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ooff[s], g.soff, 0)), t);
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) f[e] += t[e];
+                        }
                     }
                 } else {
 #pragma unroll
@@ -335,7 +359,7 @@ void conv1d_buf_kernel(const BufParams p) {
                 outv[s] = ChunkOps<T>::pack(f);
             }
         }
-        if constexpr (STATS) {
+        if constexpr (STATS == 1) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 float f[EPC];
@@ -349,7 +373,29 @@ void conv1d_buf_kernel(const BufParams p) {
                 }
             }
         }
-        if constexpr (STATS) {             // keep the statistics arithmetic above the stores (see the note below)
+        if constexpr (STATS == 2) {
+            // the stored (rounded) output is what the BatchNorm backward reads back as its incoming gradient
+            u32x4 zv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zv[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ooff[s], g.soff, 0);
+            float mk[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) mk[e] = p.bmask ? p.bmask[g.img * C + (tid % CH) * EPC + e] : 1.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float f[EPC], z[EPC];
+                ChunkOps<T>::unpack(outv[s], f);
+                ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, zv[s]), z);       // masked lanes read zeros and f is gated by `live`
+                const float live = ooff[s] == ERF_OOB ? 0.f : 1.f;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float v = f[e] * live * mk[e];
+                    ssum[e] += v;
+                    ssq[e] += v * ((z[e] - bmu[e]) * bis[e]);
+                }
+            }
+        }
+        if constexpr (STATS != 0) {        // keep the statistics arithmetic above the stores (see the note below)
 #pragma unroll
             for (int e = 0; e < EPC; ++e) asm volatile("" : "+v"(ssum[e]), "+v"(ssq[e])::"memory");
         }
@@ -369,7 +415,7 @@ void conv1d_buf_kernel(const BufParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
 
-    if constexpr (STATS) {
+    if constexpr (STATS != 0) {
         // thread `tid` owns chunk tid % CH: the NT / CH owners of a chunk meet in LDS, summed in double in a fixed order
         __syncthreads();
         float* red = (float*)smem;
@@ -436,8 +482,12 @@ static int launch_buf(BufParams p, int N, int H, int W, int axis, int* groups, h
             return ERF_ELAUNCH;                                                                                     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, stream, p);                                        \
     }
-    if (p.stats) { if (post) ERF_LAUNCH_BUF(true, true) else ERF_LAUNCH_BUF(false, true) }
-    else { if (post) ERF_LAUNCH_BUF(true, false) else ERF_LAUNCH_BUF(false, false) }
+    if (p.bz) {
+        if (!p.stats || !post || !p.bmean || !p.binvstd) return ERF_EINVAL;
+        if (p.bmask && axis != 0) return ERF_EUNSUPPORTED;       // the mask is per image: tiles must not mix images
+        ERF_LAUNCH_BUF(true, 2)
+    } else if (p.stats) { if (post) ERF_LAUNCH_BUF(true, 1) else ERF_LAUNCH_BUF(false, 1) }
+    else { if (post) ERF_LAUNCH_BUF(true, 0) else ERF_LAUNCH_BUF(false, 0) }
 #undef ERF_LAUNCH_BUF
     return erf_check_launch();
 }
@@ -447,12 +497,15 @@ int conv1d_buf_max_groups() { return 512; }
 
 int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, const void* residual,
                       const void* gate, double* stats, int* groups, int dtype, int N, int H, int W, int C, int axis, int dilation,
-                      int relu, hipStream_t stream) {
+                      int relu, hipStream_t stream, const Conv1dBnTail* tail) {
     static const int off = getenv("ERF_CONV1D_BUF_OFF") ? atoi(getenv("ERF_CONV1D_BUF_OFF")) : 0;
     if (off) return ERF_EUNSUPPORTED;
     BufParams p{};
     p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual; p.gate = gate; p.stats = stats;
     p.d = dilation; p.relu = relu;
+    if (tail) {
+        p.bz = tail->z; p.bmean = tail->mean; p.binvstd = tail->invstd; p.bmask = tail->mask; p.gate_after = tail->gate_after;
+    }
     if ((long long)N * H * W >= (1LL << 31)) return ERF_EUNSUPPORTED;
     int rc = ERF_EUNSUPPORTED;
     if (dtype == 1) {

@@ -250,7 +250,13 @@ int erf_output_conv_wgrad(const void* x, const void* patches, float* dw, int dty
  *   size erf_bn_workspace_bytes(C)).
  * erf_conv1d_dgrad_bias: erf_conv1d_dgrad plus dbias[c] = sum_p dx[p][c], the bias gradient of the
  *   convolution whose output gradient dx is.
- * Both return ERF_EUNSUPPORTED without launching when the shape needs the generic kernels: issue the two
+ * erf_conv1d_dgrad_bn_backward: dx = [gate > 0] * (erf_conv1d_dgrad(dy) + residual) followed by erf_bn_backward of
+ *   the BatchNorm whose output gradient dx is (autograd of train/erfnet.py:61-62 `bn1 -> relu`, :69-74
+ *   `bn2 -> dropout -> relu(output + input)`, :20-21 / :153-154 of the samplers): that layer's two reductions are
+ *   taken in the convolution's epilogue, then dz, dgamma, dbeta as erf_bn_backward writes them (gate already
+ *   applied, bn_mask = the Dropout2d multipliers [N][C] or NULL; with bn_mask the convolution must run along H).
+ *   workspace: erf_bn_workspace_bytes(C).
+ * All three return ERF_EUNSUPPORTED without launching when the shape needs the generic kernels: issue the
  * separate calls then. */
 int erf_conv1d_factorized_bn(const void* x, void* z, const void* packed, const float* bias, int dtype, int N, int H, int W,
                              int C, int axis, int dilation, const float* gamma, const float* beta, float* running_mean,
@@ -258,6 +264,10 @@ int erf_conv1d_factorized_bn(const void* x, void* z, const void* packed, const f
                              float* shift, void* workspace, void* stream);
 int erf_conv1d_dgrad_bias(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual, int dtype,
                           int N, int H, int W, int C, int axis, int dilation, float* dbias, void* workspace, void* stream);
+int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual,
+                                 int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
+                                 const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
+                                 int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
 
 /* ---- classifier head of the ImageNet pre-training variant, train/erfnet_imagenet.py:97-120 ----
  * Features.forward after the encoder: MaxPool2d(2, stride 2) -> AvgPool2d(14, 1, 0) on the 28x28 map

@@ -524,6 +524,56 @@ def test_trainer_checkpoint_resume_is_interchangeable_with_torch_adam():
     assert trb.step_count == 2
 
 
+@pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 28),
+                                                      (torch.bfloat16, 8e-2, (1, 512, 1024), 34)])
+def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, expected):
+    """The BatchNorm backward whose reductions ride in the preceding data-gradient convolution (in-block bn1, and the
+    previous block's last BatchNorm across the block boundary) gives the gradients of the separate-kernel path.
+    fp32: same values up to the summation order (2e-5).  bf16: every dz is rounded to bf16, so a different summation
+    order flips roundings that 70 layers of backward amplify; the two paths agree to a few percent (bar 8e-2), the
+    same spread two bf16 runs of the separate-kernel path show between batch sizes."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd import autograd as ag
+    sd = O.synthetic_state(O.erfnet_template(20))
+    n, h, w = shape
+    x = S.synthetic_images(n, h, w, seed=93).to(DEV)
+    up = upstream((n, 20, h, w), 93).to(DEV)
+
+    def run(fuse):
+        m = E.ERFNet(20)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        m.compute_dtype = torch.bfloat16 if dtype == torch.bfloat16 else None
+        for mod in m.modules():
+            if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
+                gen = torch.Generator().manual_seed(mod.conv3x1_1.out_channels + mod.dilated)
+                keep = (torch.rand(n, mod.conv3x1_1.out_channels, generator=gen) > mod.dropout.p).float()
+                mod.__dict__["_erf_forced_mask"] = keep / (1 - mod.dropout.p)
+        old, ag.FUSE_BN_BACKWARD = ag.FUSE_BN_BACKWARD, fuse
+        n0 = ag.FUSED_BN_BACKWARD_CALLS[0]
+        try:
+            y = m(x)
+            y.backward(up)
+        finally:
+            ag.FUSE_BN_BACKWARD = old
+        return m, y.detach(), ag.FUSED_BN_BACKWARD_CALLS[0] - n0
+
+    ma, ya, na = run(True)
+    mb, yb, nb = run(False)
+    # 17 in-block bn1 + the 17 block-final BatchNorms that are followed by a non_bottleneck_1d (34 of the 39); on the
+    # small input the dilation-16 blocks (two lattice rows per residue class) fall back to the separate kernels
+    assert nb == 0 and na == expected, (na, nb)
+    assert torch.equal(ya, yb)
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None
+            continue
+        if pre_bn_bias(k):
+            continue
+        err = rel_err(p.grad.cpu(), q.grad.cpu())
+        assert err <= tol, (k, err)
+
+
 def test_caches_follow_raw_pointer_parameter_updates():
     """The fused optimiser writes parameters through raw pointers (no torch version bump): eval-mode caches of
     packed weights / folded BatchNorm and the trainer's packed-weight bank must still see the new values."""
