@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["auto", "infer", "train", "imagenet"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "infer", "train", "imagenet", "multi"], default="auto")
+    ap.add_argument("--classes", type=int, default=20, help="ERFNet(num_classes) of the inference leg (6: the 1024x2048 config)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 16 inference, 6 training)")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
@@ -87,9 +88,9 @@ def max_over_ranks(x: float, world, dev) -> float:
     return float(t.item())
 
 
-def build_model(dev, dtype_name):
+def build_model(dev, dtype_name, classes=20):
     from erfnet_pytorch_amd import erfnet as E, synthetic as S
-    model = E.ERFNet(20)
+    model = E.ERFNet(classes)
     S.load_synthetic(model)
     model = model.to(dev).eval()
     model.compute_dtype = torch.bfloat16 if dtype_name == "bf16" else None
@@ -206,11 +207,11 @@ def roofline_infer(model, x, dtype_name):
 def run_infer(args, world, rank, dev):
     from erfnet_pytorch_amd.iouEval import iouEval
     batch = args.batch or 16
-    model = build_model(dev, args.dtype)
+    model = build_model(dev, args.dtype, args.classes)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(batch, 3, args.height, args.width, device=dev, generator=gen)
-    target = torch.randint(0, 20, (batch, 1, args.height, args.width), device=dev, generator=gen)
-    ev = iouEval(20)
+    target = torch.randint(0, args.classes, (batch, 1, args.height, args.width), device=dev, generator=gen)
+    ev = iouEval(args.classes)
 
     def step():
         with torch.no_grad():
@@ -243,7 +244,7 @@ def run_infer(args, world, rank, dev):
         "value": world * batch * args.steps / elapsed, "unit": "img/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"ERFNet(20) inference + fused argmax + iouEval histogram, batch {batch}/GPU, "
+        "config": {"workload": f"ERFNet({args.classes}) inference + fused argmax + iouEval histogram, batch {batch}/GPU, "
                                f"3x{args.height}x{args.width}, {'independent shards per rank' if world > 1 else 'single GPU'}",
                    "hip_graph": graph is not None, "synthetic_miou": miou},
     }
@@ -253,6 +254,45 @@ def run_infer(args, world, rank, dev):
         if not args.no_roofline:
             res["roofline"] = roofline_infer(model, x, args.dtype)
     return res
+
+
+def run_multi(args, world, rank, dev):
+    """Multi-task variant (train/multi_models.py): shared encoder, two regression decoders with skips, classifier."""
+    from erfnet_pytorch_amd import multi_models as MM, synthetic as S
+    batch = args.batch or 8
+    model = MM.Multi_models(14)
+    S.load_synthetic(model)
+    model = model.to(dev).eval()
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(batch, 3, args.height, args.width, device=dev, generator=gen)
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+    run = graph.replay if graph is not None else step
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    return {"metric": "img/s Multi_models inference (traversability + depth + class)", "value": world * batch * args.steps / elapsed,
+            "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Multi_models(14) eval, batch {batch}/GPU, 3x{args.height}x{args.width}", "hip_graph": graph is not None}}
 
 
 def run_train(args, world, rank, dev):
@@ -272,6 +312,8 @@ def main():
     if args.mode == "imagenet":
         from erfnet_pytorch_amd import trainer
         res = trainer.bench_imagenet(args, world, rank, dev, barrier, max_over_ranks)
+    elif args.mode == "multi":
+        res = run_multi(args, world, rank, dev)
     elif args.mode == "train":
         res = run_train(args, world, rank, dev)
     else:
@@ -282,7 +324,7 @@ def main():
             tr = run_train(targs, world, rank, dev)
             res["training"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "model_tflops")}
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.mode != "multi":
             res["cpu_baseline"] = cpu_baseline(args.height, args.width)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -104,6 +104,15 @@ SIGNATURES = {
     "erf_stem_wgrad": (I, [P, P, P, I, I, I, I, P, c_size_t, P]),
     "erf_upsampler_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
     "erf_output_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P]),
+    "erf_conv3x3_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_conv3x3_pack": (I, [P, P, I, I, I, I, P]),
+    "erf_conv3x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "erf_maxpool2x2_affine": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "erf_convT2x2s2_packed_bytes": (c_size_t, [I, I, I]),
+    "erf_convT2x2s2_pack": (I, [P, P, I, I, I, P]),
+    "erf_convT2x2s2": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "erf_spatial_mean": (I, [P, I, P, I, I, I, I, P]),
+    "erf_image_to_nhwc_channels": (I, [P, I, P, I, I, I, I, I, P]),
     "erf_pointwise_grad_channels": (I, [I]),
     "erf_pointwise_grad_nhwc": (I, [P, I, P, I, I, I, I, I, P]),
     "erf_pointwise_dgrad_packed_bytes": (c_size_t, [I, I, I]),

@@ -6,6 +6,7 @@
 #include "pack.cuh"
 #include "misc.cuh"
 #include "conv1d.cuh"
+#include "train.cuh"
 
 static inline bool dtype_ok(int d) { return d == ERF_F32 || d == ERF_BF16; }
 static inline int ct_of(int cout) { return (cout + 15) / 16; }
@@ -127,7 +128,7 @@ size_t erf_upsampler_packed_bytes(int dtype, int Cin, int Cout) {
 }
 
 int erf_upsampler_pack(const float* w, void* packed, int dtype, int Cin, int Cout, void* stream) {
-    if (!w || !packed || !dtype_ok(dtype) || !((Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 16))) return ERF_EINVAL;
+    if (!w || !packed || !dtype_ok(dtype) || !((Cin == 128 && (Cout == 64 || Cout == 16)) || (Cin == 64 && Cout == 16))) return ERF_EINVAL;
     long long off = 0;
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
@@ -149,7 +150,7 @@ int erf_upsampler_pack(const float* w, void* packed, int dtype, int Cin, int Cou
 int erf_upsampler_convT3x3s2(const void* x, void* y, const void* packed, const float* scale, const float* shift, int dtype,
                              int N, int Hin, int Win, int Cin, int Cout, int relu, void* stream) {
     if (!x || !y || !packed || !dtype_ok(dtype) || N <= 0 || Hin <= 0 || Win <= 0) return ERF_EINVAL;
-    if (!((Cin == 128 && Cout == 64) || (Cin == 64 && Cout == 16))) return ERF_EUNSUPPORTED;
+    if (!((Cin == 128 && (Cout == 64 || Cout == 16)) || (Cin == 64 && Cout == 16))) return ERF_EUNSUPPORTED;   // 128 -> 16: multi_models.py:127
     {
         const int rc = up_launch(x, y, packed, scale, shift, dtype, N, Hin, Win, Cin, Cout, relu, (hipStream_t)stream);
         if (rc != ERF_EUNSUPPORTED) return rc;
@@ -224,6 +225,96 @@ int erf_pointwise_conv(const void* x, void* y, const void* packed, const float* 
     GConvPhase& ph = p.ph[0];
     ph.oh = ph.ow = 0; ph.ntaps = 1; ph.dh[0] = ph.dw[0] = 0; ph.w_chunk_off = 0; ph.ksteps = gconv_ksteps(dtype, Cin, 1);
     return gconv_launch(p, dtype, Cin, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ Multi_models (train/multi_models.py), inference
+// The multi-task variant reuses the blocks above plus four generic pieces on the gather-form convolution.
+static bool conv3x3_shape_ok(int Cin, int Cout) {
+    return (Cin == 16 && (Cout == 16 || Cout == 64)) || (Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 64);
+}
+
+size_t erf_conv3x3_packed_bytes(int dtype, int Cin, int Cout) {
+    if (!dtype_ok(dtype) || !conv3x3_shape_ok(Cin, Cout)) return 0;
+    return (size_t)gconv_phase_chunks(ct_of(Cout), gconv_ksteps(dtype, Cin, 9)) * 16;
+}
+
+int erf_conv3x3_pack(const float* w, void* packed, int dtype, int Cin, int Cin_valid, int Cout, void* stream) {
+    if (!w || !packed || !dtype_ok(dtype) || !conv3x3_shape_ok(Cin, Cout) || Cin_valid < 1 || Cin_valid > Cin) return ERF_EINVAL;
+    PackParams p{};
+    p.src = w; p.dst = packed; p.cin = Cin; p.cin_valid = Cin_valid == Cin ? 0 : Cin_valid; p.cout_virtual = Cout; p.ncp = NO_PHASES;
+    p.nc_valid = Cout; p.s_co = 9LL * Cin_valid; p.s_ci = 9; p.s_phase = 0; p.ntaps = 9;      // weight [Cout][Cin_valid][3][3]
+    for (int t = 0; t < 9; ++t) p.toff[t] = t;
+    p.ct = ct_of(Cout); p.ksteps = gconv_ksteps(dtype, Cin, 9);
+    return pack_launch(p, dtype, (hipStream_t)stream);
+}
+
+int erf_conv3x3(const void* x, void* y, const void* packed, const float* scale, const float* shift, int dtype, int N, int Hin,
+                int Win, int Cin, int Cout, int stride, int relu, void* stream) {
+    if (!x || !y || !packed || !dtype_ok(dtype) || N <= 0 || Hin <= 0 || Win <= 0 || (stride != 1 && stride != 2)) return ERF_EINVAL;
+    if (!conv3x3_shape_ok(Cin, Cout)) return ERF_EUNSUPPORTED;
+    const int Ho = (Hin + stride - 1) / stride, Wo = (Win + stride - 1) / stride;      // kernel 3, padding 1
+    GConvParams p{};
+    p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift;
+    p.N = N; p.Hin = Hin; p.Win = Win; p.ldx = Cin; p.Hb = Ho; p.Wb = Wo; p.Hout = Ho; p.Wout = Wo;
+    p.ldy = Cout; p.Cout = Cout; p.Si = stride; p.So = 1; p.relu = relu; p.out_mode = 0; p.nphase = 1;
+    GConvPhase& ph = p.ph[0];
+    ph.ntaps = 9; ph.ksteps = gconv_ksteps(dtype, Cin, 9);
+    for (int t = 0; t < 9; ++t) { ph.dh[t] = t / 3 - 1; ph.dw[t] = t % 3 - 1; }
+    return gconv_launch(p, dtype, Cin, (hipStream_t)stream);
+}
+
+int erf_maxpool2x2_affine(const void* x, void* y, const float* scale, const float* shift, int dtype, int N, int Hin, int Win,
+                          int C, int relu, void* stream) {
+    if (!x || !y || !dtype_ok(dtype) || N <= 0 || Hin < 2 || Win < 2 || ((Hin | Win) & 1) || C <= 0) return ERF_EINVAL;
+    return pool_affine_launch(x, y, scale, shift, dtype, N, Hin, Win, C, C, 0, relu, (hipStream_t)stream);
+}
+
+size_t erf_convT2x2s2_packed_bytes(int dtype, int Cin, int Cout) {
+    if (!dtype_ok(dtype) || Cin != 32 || Cout < 1 || Cout > 16) return 0;
+    return (size_t)4 * gconv_phase_chunks(1, gconv_ksteps(dtype, Cin, 1)) * 16;
+}
+
+int erf_convT2x2s2_pack(const float* w, void* packed, int dtype, int Cin, int Cout, void* stream) {
+    if (!w || !packed || !dtype_ok(dtype) || Cin != 32 || Cout < 1 || Cout > 16) return ERF_EINVAL;
+    const long long per = gconv_phase_chunks(1, gconv_ksteps(dtype, Cin, 1));
+    for (int ph = 0; ph < 4; ++ph) {
+        PackParams p{};
+        p.src = w; p.dst = (char*)packed + ph * per * 16; p.cin = Cin; p.cout_virtual = Cout; p.ncp = NO_PHASES; p.nc_valid = Cout;
+        p.s_co = 4; p.s_ci = 4LL * Cout; p.ntaps = 1; p.toff[0] = ph;               // ConvTranspose2d weight [Cin][Cout][2][2]
+        p.ct = 1; p.ksteps = gconv_ksteps(dtype, Cin, 1);
+        const int rc = pack_launch(p, dtype, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ERF_OK;
+}
+
+int erf_convT2x2s2(const void* x, void* y, const void* packed, const float* bias, int out_f32, int dtype, int N, int Hin, int Win,
+                   int Cin, int Cout, void* stream) {
+    if (!x || !y || !packed || !dtype_ok(dtype) || N <= 0 || Hin <= 0 || Win <= 0) return ERF_EINVAL;
+    if (Cin != 32 || Cout < 1 || Cout > 16) return ERF_EUNSUPPORTED;
+    GConvParams p{};
+    p.x = x; p.y = y; p.w = packed; p.shift = bias;
+    p.N = N; p.Hin = Hin; p.Win = Win; p.ldx = Cin; p.Hb = Hin; p.Wb = Win; p.Hout = 2 * Hin; p.Wout = 2 * Win;
+    p.ldy = Cout; p.Cout = Cout; p.Si = 1; p.So = 2; p.out_mode = out_f32 ? 2 : 1; p.nphase = 4;
+    const long long per = gconv_phase_chunks(1, gconv_ksteps(dtype, Cin, 1));
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            GConvPhase& ph = p.ph[a * 2 + b];
+            ph.oh = a; ph.ow = b; ph.ntaps = 1; ph.dh[0] = ph.dw[0] = 0;
+            ph.ksteps = gconv_ksteps(dtype, Cin, 1);
+            ph.w_chunk_off = (int)((a * 2 + b) * per);
+        }
+    return gconv_launch(p, dtype, Cin, (hipStream_t)stream);
+}
+
+int erf_spatial_mean(const void* x, int dtype, float* feat, int N, int H, int W, int C, void* stream) {
+    if (!x || !feat || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return ERF_EINVAL;
+    return spatial_mean_launch(x, dtype, feat, N, (long long)H * W, C, (hipStream_t)stream);
+}
+
+int erf_image_to_nhwc_channels(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, int cpad, void* stream) {
+    if (!x_nchw || !out || !dtype_ok(dtype) || !dtype_ok(x_dtype) || N <= 0 || cpad < 3) return ERF_EINVAL;
+    return image_pad_launch(x_nchw, x_dtype, out, dtype, N, (long long)H * W, cpad, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ layout glue and metrics

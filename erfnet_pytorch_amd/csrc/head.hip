@@ -22,6 +22,30 @@ __global__ __launch_bounds__(256) void pool_mean_fwd_kernel(const T* __restrict_
     feat[idx] = s / (float)((H / 2) * (W / 2));
 }
 
+// feat[n][c] = mean over all H x W positions (fp32 output)
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const T* __restrict__ x, float* __restrict__ feat, int N, long long HW, int C) {
+    // one block per image, thread t owns channels t, t + 256, ...; rows of C channels are read coalesced
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const T* p = x + (long long)n * HW * C + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long long i = 0;
+        for (; i + 3 < HW; i += 4) {
+            s0 += Elem<T>::ld(p + i * C); s1 += Elem<T>::ld(p + (i + 1) * C);
+            s2 += Elem<T>::ld(p + (i + 2) * C); s3 += Elem<T>::ld(p + (i + 3) * C);
+        }
+        for (; i < HW; ++i) s0 += Elem<T>::ld(p + i * C);
+        feat[n * C + c] = ((s0 + s1) + (s2 + s3)) / (float)HW;
+    }
+}
+
+int spatial_mean_launch(const void* x, int dtype, float* feat, int N, long long HW, int C, hipStream_t stream) {
+    if (dtype == 1) hipLaunchKernelGGL(spatial_mean_kernel<bf16raw>, dim3(N), dim3(256), 0, stream, (const bf16raw*)x, feat, N, HW, C);
+    else hipLaunchKernelGGL(spatial_mean_kernel<float>, dim3(N), dim3(256), 0, stream, (const float*)x, feat, N, HW, C);
+    return erf_check_launch();
+}
+
 // dx = dfeat[n][c] / (#windows) at the first maximum of each 2x2 window (row-major scan, as torch), 0 elsewhere
 template <typename T>
 __global__ __launch_bounds__(256) void pool_mean_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dfeat, T* __restrict__ dx,

@@ -55,6 +55,7 @@ int wgrad1d_launch(const void* x, const void* dz, float* dw, int dtype, int N, i
                    const PackParams& map, float* workspace, size_t workspace_bytes, hipStream_t stream);
 
 // ---- classifier head of the ImageNet variant (head.hip)
+int spatial_mean_launch(const void* x, int dtype, float* feat, int N, long long HW, int C, hipStream_t stream);
 int pool_mean_fwd_launch(const void* x, int dtype, float* feat, int N, int H, int W, int C, hipStream_t stream);
 int pool_mean_bwd_launch(const void* x, const float* dfeat, void* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);
 int linear_fwd_launch(const float* f, const float* w, const float* b, float* y, int N, int C, int K, hipStream_t stream);

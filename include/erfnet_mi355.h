@@ -185,6 +185,30 @@ int erf_adam_fused_arena(float* params, const float* grads, float* exp_avg, floa
 int erf_sgd_fused_arena(float* params, const float* grads, float* momentum_buf, long long n, double lr, double momentum,
                         double weight_decay, int first_step, double grad_scale, void* stream);
 
+/* ---- Multi_models (train/multi_models.py), inference -------------------------------------------------------
+ * The multi-task network reuses non_bottleneck_1d and UpsamplerBlock (also 128 -> 16, multi_models.py:127) and adds:
+ * erf_conv3x3: 3x3 convolution, padding 1, stride 1 or 2, y = act(scale * conv(x) + shift), NHWC in and out
+ *   (DownsamplerBlock_simplified.conv, multi_models.py:27, stride 1; Classifier conv, :190, stride 2).  Weights in
+ *   nn.Conv2d layout [Cout][Cin_valid][3][3]; x carries Cin >= Cin_valid channels (the image is widened to 16 by
+ *   erf_image_to_nhwc_channels).  Shapes: (16,16) (16,64) (64,128) (128,64).
+ * erf_maxpool2x2_affine: y = act(scale * maxpool2x2(x) + shift) -- pool, BatchNorm (folded) and ReLU of
+ *   DownsamplerBlock_simplified.forward (multi_models.py:31-36) in one pass.
+ * erf_convT2x2s2: ConvTranspose2d(32, Cout, 2, stride 2) + bias -> NCHW planes (the decoders' last layer,
+ *   multi_models.py:134 / :165), weights [32][Cout][2][2].
+ * erf_spatial_mean: feat[n][c] = mean over H x W (Classifier.forward `output.mean(3).mean(2)`, multi_models.py:200). */
+size_t erf_conv3x3_packed_bytes(int dtype, int Cin, int Cout);
+int erf_conv3x3_pack(const float* w, void* packed, int dtype, int Cin, int Cin_valid, int Cout, void* stream);
+int erf_conv3x3(const void* x, void* y, const void* packed, const float* scale, const float* shift, int dtype, int N, int Hin,
+                int Win, int Cin, int Cout, int stride, int relu, void* stream);
+int erf_maxpool2x2_affine(const void* x, void* y, const float* scale, const float* shift, int dtype, int N, int Hin, int Win,
+                          int C, int relu, void* stream);
+size_t erf_convT2x2s2_packed_bytes(int dtype, int Cin, int Cout);
+int erf_convT2x2s2_pack(const float* w, void* packed, int dtype, int Cin, int Cout, void* stream);
+int erf_convT2x2s2(const void* x, void* y, const void* packed, const float* bias, int out_f32, int dtype, int N, int Hin, int Win,
+                   int Cin, int Cout, void* stream);
+int erf_spatial_mean(const void* x, int dtype, float* feat, int N, int H, int W, int C, void* stream);
+int erf_image_to_nhwc_channels(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, int cpad, void* stream);
+
 /* ---- data gradients (autograd of the layers above) --------------------------------------
  * conv1d: dx = conv1d(dy; erf_conv1d_pack(mode 1)) * [gate > 0] + residual (gate, residual may be NULL).
  * downsampler: dx = convT(dz[..., :Cout-Cin]) (pool part: erf_maxpool2x2_backward with accumulate).

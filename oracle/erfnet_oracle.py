@@ -14,6 +14,7 @@ algorithm of the reference's Python model, loss, metric and optimiser:
   decoder          /root/reference/train/erfnet.py:157-181
   erfnet           /root/reference/train/erfnet.py:271-286
   imagenet head    /root/reference/train/erfnet_imagenet.py:64-129
+  multi_models     /root/reference/train/multi_models.py:23-36,75-221 (eval forward)
   weighted CE      /root/reference/train/main.py:72-80,121,202
   class weights    /root/reference/train/main.py:92-111
   iou counts       /root/reference/train/iouEval.py:8-75
@@ -142,6 +143,46 @@ def erfnet(sd: SD, x: torch.Tensor, st: Optional[RunState] = None, only_encode: 
     if only_encode:
         return encoder(sd, x, st, predict=True)
     return decoder(sd, encoder(sd, x, st), st)
+
+
+def downsampler_simplified(sd: SD, p: str, x: torch.Tensor, st: RunState) -> torch.Tensor:
+    """train/multi_models.py:23-36: conv3x3 stride 1 -> maxpool 2x2 -> BatchNorm -> ReLU."""
+    y = F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=1, padding=1)
+    return F.relu(_bn(sd, p + ".bn", F.max_pool2d(y, 2, stride=2), st))
+
+
+def _skip_decoder(sd: SD, p: str, x, s1, s2, st: RunState) -> torch.Tensor:
+    """train/multi_models.py:116-178 (both regression decoders share this graph)."""
+    x = upsampler(sd, p + ".upblock_1.0", x, st)
+    x = nb1d(sd, p + ".upblock_1.1", x, 1, 0.0, st)
+    x = nb1d(sd, p + ".upblock_1.2", x, 1, 0.0, st)
+    x = torch.cat([x, s2], dim=1)
+    x = upsampler(sd, p + ".upblock_2.0", x, st)
+    x = nb1d(sd, p + ".upblock_2.1", x, 1, 0.0, st)
+    x = nb1d(sd, p + ".upblock_2.2", x, 1, 0.0, st)
+    x = torch.cat([x, s1], dim=1)
+    return F.conv_transpose2d(x, sd[p + ".upblock_3.0.weight"], sd[p + ".upblock_3.0.bias"], stride=2)
+
+
+def multi_models(sd: SD, x: torch.Tensor, st: Optional[RunState] = None):
+    """train/multi_models.py:205-221, eval mode: (traversability map, depth map, class logits)."""
+    st = st or RunState()
+    if st.training:
+        raise NotImplementedError("the multi-task oracle restates the eval-mode forward only")
+    s1 = downsampler_simplified(sd, "encoder.downblock_1", x, st)
+    y = downsampler_simplified(sd, "encoder.downblock_2.0", s1, st)
+    for i in range(1, 4):
+        y = nb1d(sd, f"encoder.downblock_2.{i}", y, 1, 0.03, st)
+    s2 = y
+    y = downsampler_simplified(sd, "encoder.downblock_3.0", y, st)
+    for i, d in enumerate((2, 4, 8, 16)):
+        y = nb1d(sd, f"encoder.downblock_3.{i + 1}", y, d, 0.3, st)
+    trav = _skip_decoder(sd, "decoder_traversability", y, s1, s2, st)
+    depth = _skip_decoder(sd, "decoder_depth", y, s1, s2, st)
+    c = F.conv2d(y, sd["classifier.classifier.0.weight"], sd["classifier.classifier.0.bias"], stride=2, padding=1)
+    c = F.relu(_bn(sd, "classifier.classifier.1", c, st))            # Dropout2d(0.3) is the identity in eval mode
+    c = c.mean(3).mean(2)
+    return trav, depth, F.linear(c, sd["classifier.linear.weight"], sd["classifier.linear.bias"])
 
 
 def erfnet_imagenet(sd: SD, x: torch.Tensor, st: Optional[RunState] = None) -> torch.Tensor:
@@ -319,6 +360,36 @@ def erfnet_template(num_classes):
 def imagenet_template(num_classes=1000):
     t = encoder_template(0, prefix="features.encoder", with_output_conv=False, bn_last=True)
     t["classifier.linear.weight"] = (num_classes, 128)
+    t["classifier.linear.bias"] = (num_classes,)
+    return t
+
+
+def multi_models_template(num_classes=14):
+    """Keys and shapes of Multi_models(num_classes).state_dict() (train/multi_models.py:205-213), in registration order."""
+    def simp(p, cin, cout):
+        t = {p + ".conv.weight": (cout, cin, 3, 3), p + ".conv.bias": (cout,)}
+        t.update(_bn_t(p + ".bn", cout))
+        return t
+    t = simp("encoder.downblock_1", 3, 16)
+    t.update(simp("encoder.downblock_2.0", 16, 64))
+    for i in range(1, 4):
+        t.update(nb_template(f"encoder.downblock_2.{i}", 64))
+    t.update(simp("encoder.downblock_3.0", 64, 128))
+    for i in range(1, 5):
+        t.update(nb_template(f"encoder.downblock_3.{i}", 128))
+    for dec in ("decoder_traversability", "decoder_depth"):
+        t.update(up_template(dec + ".upblock_1.0", 128, 64))
+        t.update(nb_template(dec + ".upblock_1.1", 64))
+        t.update(nb_template(dec + ".upblock_1.2", 64))
+        t.update(up_template(dec + ".upblock_2.0", 128, 16))
+        t.update(nb_template(dec + ".upblock_2.1", 16))
+        t.update(nb_template(dec + ".upblock_2.2", 16))
+        t[dec + ".upblock_3.0.weight"] = (32, 1, 2, 2)
+        t[dec + ".upblock_3.0.bias"] = (1,)
+    t["classifier.classifier.0.weight"] = (64, 128, 3, 3)
+    t["classifier.classifier.0.bias"] = (64,)
+    t.update(_bn_t("classifier.classifier.1", 64))
+    t["classifier.linear.weight"] = (num_classes, 64)
     t["classifier.linear.bias"] = (num_classes,)
     return t
 

@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/train")
 
 import erfnet as ref_erfnet                  # noqa: E402  (reference)
+import multi_models as ref_multi             # noqa: E402  (reference)
 import erfnet_imagenet as ref_imagenet       # noqa: E402  (reference)
 import iouEval as ref_iou                    # noqa: E402  (reference)
 
@@ -351,6 +352,28 @@ def g7_encoder_only():
     np.savez_compressed(os.path.join(HERE, "g7_encoder_only.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G8
+def g8_multi_models():
+    """train/multi_models.py Multi_models(14).eval(): the three outputs, the encoder's skips, the state_dict key list."""
+    out = {}
+    m = S.load_synthetic(ref_multi.Multi_models(14)).eval()
+    out["keys"] = np.array(list(m.state_dict().keys()))
+    out["shapes"] = np.array([",".join(str(d) for d in v.shape) for v in m.state_dict().values()])
+    for tag, (n, h, w, seed) in {"a": (2, 64, 128, 81), "b": (1, 128, 256, 82)}.items():
+        x = S.synthetic_images(n, h, w, seed=seed)
+        with torch.no_grad():
+            trav, depth, cls = m(x)
+            feat, s1, s2 = m.encoder(x)
+        out[tag + "__in"] = np.array([n, h, w, seed], dtype=np.int64)
+        pack(out, tag + "_trav", trav)
+        pack(out, tag + "_depth", depth)
+        pack(out, tag + "_class", cls)
+        pack(out, tag + "_feat", feat)
+        pack(out, tag + "_skip1", s1)
+        pack(out, tag + "_skip2", s2)
+    np.savez_compressed(os.path.join(HERE, "g8_multi_models.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # e.g. `make_golden.py g7_encoder_only`: regenerate the named sets only
         for name in sys.argv[1:]:
@@ -363,6 +386,7 @@ if __name__ == "__main__":
     g5_train_steps()
     g6_imagenet()
     g7_encoder_only()
+    g8_multi_models()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -219,6 +219,36 @@ def test_full_net_bf16_vs_oracle():
     assert torch.equal(labels.cpu(), y.cpu().max(1)[1])
 
 
+@pytest.mark.parametrize("nc,shape", [(20, (2, 512, 1024)), (6, (1, 1024, 2048))])
+def test_full_size_properties(nc, shape):
+    """The benchmark configurations at their full sizes (the oracle takes seconds per image there), through properties
+    that do not depend on the size: fused labels == arg-max of the logits path bit for bit, images of a batch are
+    independent (same result alone and in a batch), the confusion matrix counts every pixel once and equals the
+    histogram of (label, prediction) pairs computed by torch."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.iouEval import iouEval
+    n, h, w = shape
+    model = E.ERFNet(nc)
+    model.load_state_dict(O.synthetic_state(O.erfnet_template(nc)))
+    model = model.to(_dev()).eval()
+    model.compute_dtype = torch.bfloat16
+    x = S.synthetic_images(n, h, w, seed=11).to(_dev())
+    with torch.no_grad():
+        logits = model(x)
+        labels = model.predict_labels(x, torch.uint8)
+        alone = model.predict_labels(x[:1].contiguous(), torch.uint8)
+    assert logits.shape == (n, nc, h, w) and labels.shape == (n, h, w)
+    assert torch.equal(labels.long(), logits.max(1)[1])
+    assert torch.equal(alone[0], labels[0])
+    target = S.synthetic_labels(n, h, w, nc, seed=12).to(_dev())
+    ev = iouEval(nc)
+    ev.addBatch(labels.unsqueeze(1), target)
+    conf = ev.confusion()
+    assert int(conf.sum()) == n * h * w
+    ref = torch.bincount((target[:, 0].long() * nc + labels.long()).reshape(-1), minlength=nc * nc).reshape(nc, nc).cpu()
+    assert torch.equal(conf.reshape(nc, nc).cpu().long(), ref)
+
+
 def test_iou_eval_exact_vs_golden_and_oracle():
     from erfnet_pytorch_amd.iouEval import iouEval
     g = load("g4_iou.npz")

@@ -251,6 +251,22 @@ def test_g7_encoder_only_stage():
     assert np.all((np.abs(ps - g["paramsum"]) <= 2e-5 * np.maximum(g["paramabs"], 1e-3))[keep])
 
 
+def test_g8_multi_models_eval():
+    """Oracle restatement of train/multi_models.py (eval) vs the reference's outputs; key list and shapes match too."""
+    g = load("g8_multi_models.npz")
+    tmpl = O.multi_models_template(14)
+    assert list(tmpl.keys()) == [str(k) for k in g["keys"]]
+    assert [",".join(str(d) for d in shp) for shp in tmpl.values()] == [str(s) for s in g["shapes"]]
+    sd = O.synthetic_state(tmpl)
+    for tag in ("a", "b"):
+        n, h, w, seed = (int(v) for v in g[tag + "__in"])
+        with torch.no_grad():
+            trav, depth, cls = O.multi_models(sd, S.synthetic_images(n, h, w, seed=seed))
+        check_packed(g, tag + "_trav", trav, 2e-5)
+        check_packed(g, tag + "_depth", depth, 2e-5)
+        check_packed(g, tag + "_class", cls, 2e-5)
+
+
 def test_g6_imagenet_encoder_classifier():
     g = load("g6_imagenet.npz")
     sd = O.synthetic_state(O.imagenet_template(1000))
