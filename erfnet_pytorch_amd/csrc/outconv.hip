@@ -11,7 +11,10 @@
 #include "misc.cuh"
 #include "conv1d_tile.cuh"
 
-template <typename T, int CT, int PT>
+// STAGE (fp32 logits, Win a multiple of 16): a tile's 16 input pixels are 32 consecutive output columns of two rows; the
+// wave parks its logits in LDS as [class][row][32 columns] and writes them back as 16-byte pieces, 128 contiguous bytes
+// per (class, row), instead of one scattered 4-byte store per lane and class.
+template <typename T, int CT, int PT, bool STAGE>
 __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, const i32x4* __restrict__ w,
                                                       const float* __restrict__ bias, void* __restrict__ logits,
                                                       int logits_mode, void* __restrict__ labels, int label_bytes, int N,
@@ -23,6 +26,9 @@ __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, c
     const unsigned P = (unsigned)N * Hin * Win;
     const unsigned tile0 = (blockIdx.x * 4 + wave) * (16 * PT);
     const int Hout = 2 * Hin, Wout = 2 * Win;
+
+    __shared__ float stage[STAGE ? 4 * CT * 4 * 64 : 1];
+    float* const st = stage + (STAGE ? wave * CT * 4 * 64 : 0);
 
     i32x4 a[CT];
 #pragma unroll
@@ -59,7 +65,9 @@ __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, c
                 const int cls = 4 * c + e;
                 if (cls < nc) {                                  // wave-uniform
                     const float val = acc[c][e] + bs[c][e];
-                    if (logits_mode && pv) {
+                    if constexpr (STAGE) {
+                        st[cls * 64 + (q >> 1) * 32 + 2 * r16 + (q & 1)] = val;
+                    } else if (logits_mode && pv) {
                         const long long o = (((long long)n * nc + cls) * Hout + oh) * Wout + ow;
                         if (logits_mode == 2) ((float*)logits)[o] = val;
                         else Elem<T>::st((T*)logits + o, val);
@@ -67,6 +75,26 @@ __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, c
                     if (val > bv) { bv = val; bi = cls; }        // first maximum wins, as torch.max(1)
                 }
             }
+        if constexpr (STAGE) {
+            // the tile is whole (P is a multiple of 16) and lies in one input row: lane 0's pixel gives its origin
+            const unsigned p0 = tile0 + t * 16;
+            __builtin_amdgcn_wave_barrier();               // the wave's own LDS traffic is in order: its writes are visible to its reads
+            if (p0 < P) {
+                const unsigned rest0 = fast_div(p0, fW);
+                const int j0 = (int)(p0 - rest0 * fW.div);
+                const unsigned n0 = fast_div(rest0, fH);
+                const int i0 = (int)(rest0 - n0 * fH.div);
+                const int sub = lane >> 4, row = (lane >> 3) & 1, col4 = (lane & 7) * 4;
+                for (int c0 = 0; c0 < nc; c0 += 4) {
+                    const int cls = c0 + sub;
+                    if (cls < nc) {
+                        const f32x4 v = *(const f32x4*)(st + cls * 64 + row * 32 + col4);
+                        *(f32x4*)((float*)logits + (((long long)n0 * nc + cls) * Hout + 2 * i0 + row) * Wout + 2 * j0 + col4) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();               // ... and the next tile's writes stay behind these reads
+        }
         if (labels) {
             const long long o = ((long long)n * Hout + oh) * Wout + ow;
             if (label_bytes == 1) {
@@ -88,8 +116,12 @@ static int outconv_dispatch(int ct, dim3 grid, hipStream_t stream, const T* x, c
     const FastDiv fW = make_fastdiv(Win), fH = make_fastdiv(Hin);
 #define OC(CTV)                                                                                                     \
     case CTV:                                                                                                       \
-        hipLaunchKernelGGL((outconv_kernel<T, CTV, 4>), grid, dim3(256), 0, stream, x, w, bias, logits, logits_mode, \
-                           labels, label_bytes, N, Hin, Win, nc, fW, fH);                                           \
+        if (logits_mode == 2 && (Win & 15) == 0)                                                                    \
+            hipLaunchKernelGGL((outconv_kernel<T, CTV, 4, true>), grid, dim3(256), 0, stream, x, w, bias, logits,       \
+                               logits_mode, labels, label_bytes, N, Hin, Win, nc, fW, fH);                              \
+        else                                                                                                        \
+            hipLaunchKernelGGL((outconv_kernel<T, CTV, 4, false>), grid, dim3(256), 0, stream, x, w, bias, logits,      \
+                               logits_mode, labels, label_bytes, N, Hin, Win, nc, fW, fH);                              \
         break;
     switch (ct) {
         OC(1) OC(2) OC(3) OC(4) OC(5) OC(6) OC(7) OC(8)
