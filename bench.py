@@ -52,8 +52,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="auto mode: skip the training leg")
     ap.add_argument("--train-batch", type=int, default=6)
-    ap.add_argument("--train-steps", type=int, default=10)
-    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--train-steps", type=int, default=30)
+    ap.add_argument("--train-warmup", type=int, default=5)
     return ap.parse_args()
 
 
