@@ -10,6 +10,7 @@ the parameters' own torch layouts whatever the activation dtype (fp32 or bf16).
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 
@@ -112,7 +113,7 @@ def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=No
 # Backward: the consumer leaves a one-slot hand-off that the very next block backward takes (or discards).
 FUSE_BN_BACKWARD = os.environ.get("ERF_FUSE_BN_BACKWARD", "1") != "0"
 FUSED_BN_BACKWARD_CALLS = [0]             # diagnostic counter (tests check that the fused path is the one that runs)
-_HANDOFF = [None]
+_HANDOFF = threading.local()             # one slot per backward thread (autograd runs one thread per device)
 
 
 class BnTail:
@@ -136,10 +137,12 @@ def _tail_of(x, xh):
 
 
 def _take_handoff(g):
-    h, _HANDOFF[0] = _HANDOFF[0], None
+    h = getattr(_HANDOFF, "slot", None)
+    _HANDOFF.slot = None
     if h is not None and h[0] == g.data_ptr() and h[1] == tuple(g.shape):
         return h[2]
-    return None
+    return None           # nothing handed over (or not for this tensor): the caller runs its BatchNorm backward itself,
+                          # which gives the same result on an already-gated gradient
 
 
 def conv1d_dgrad_bn_backward(dy, packed_t, gate, residual, axis, dilation, z, mean, invstd, gamma, mask, batch_stats,
@@ -331,7 +334,7 @@ class _NB1dFn(torch.autograd.Function):
                                              psk.out(t.prefix + ".weight", (c,), dev), psk.out(t.prefix + ".bias", (c,), dev))
         if fused is not None:
             dx = fused[0]
-            _HANDOFF[0] = (dx.data_ptr(), tuple(dx.shape), fused[1:])
+            _HANDOFF.slot = (dx.data_ptr(), tuple(dx.shape), fused[1:])
         else:
             dx = conv1d_dgrad(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), None, g_res, AXIS_H, 1)
         return (ops.to_nchw_view(dx), None) + sk.ret(dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)
