@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates profiles/r01_* on the GPU box: the unprofiled bench line, the rocprofv3 kernel-trace summary of the same
 # command, the HBM-traffic counters (separate FETCH_SIZE / WRITE_SIZE passes) and the matrix-core utilisation pass.
-# Run from the repository root:  bash scripts/refresh_profiles.sh   (outputs land in gpurun_out/, summaries in profiles/)
+# Run from the repository root:  bash scripts/refresh_profiles.sh   (outputs land in gpurun_out/r01/, summaries in profiles/).
+# Through gpurun only gpurun_out/ comes back: afterwards  cp gpurun_out/r01/r01_* profiles/
 set -eo pipefail
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/r01
