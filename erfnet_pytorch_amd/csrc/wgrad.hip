@@ -161,14 +161,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // dW[map(row, tap, ci)] = sum_wg partial[wg][row][tap*CIN + ci]
-// Block = 32 consecutive elements x 8 slices of the workgroup range; every slice sums its partials in a
+// Block = E consecutive elements x 256 / E slices of the workgroup range; every slice sums its partials in a
 // fixed order (four chains, so the loads overlap), the slices meet in LDS and are added in slice order.
+// E = 32 for the usual few hundred partials, E = 8 (32 slices) when small tiles were spread over many workgroups.
+template <int E>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int rows_pad,
                                                            int ncols_pad, int cin, const PackParams m, float* __restrict__ dw) {
-    __shared__ double sh[8][32];
+    constexpr int S = 256 / E;
+    __shared__ double sh[S][E];
     const int total = m.cout_virtual * m.ntaps * cin;
-    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + e;
+    const int e = threadIdx.x % E, sl = threadIdx.x / E;
+    const int idx = blockIdx.x * E + e;
     bool valid = idx < total;
     int col = 0, row = 0, tap = 0, ci = 0, phase = 0, cls = 0;
     if (valid) {
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (valid) {
         const long long stride = (long long)rows_pad * ncols_pad;
         const float* src = partial + (long long)row * ncols_pad + col;
-        const int per = (nwg + 7) / 8;
+        const int per = (nwg + S - 1) / S;
         int g = sl * per;
         const int g1 = g + per < nwg ? g + per : nwg;
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (sl == 0 && valid) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += sh[k][e];
+        for (int k = 0; k < S; ++k) s += sh[k][e];
         dw[(long long)cls * m.s_co + (long long)phase * m.s_phase + (long long)ci * m.s_ci + m.toff[tap]] = (float)s;
     }
 }
@@ -205,13 +208,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_pad, int cin, const PackParams& m, float* dw,
                         hipStream_t stream) {
     const int total = m.cout_virtual * m.ntaps * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, partial, nwg, rows_pad, ncols_pad, cin, m, dw);
+    if (nwg >= 1024)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((total + 7) / 8), dim3(256), 0, stream, partial, nwg, rows_pad, ncols_pad, cin, m, dw);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((total + 31) / 32), dim3(256), 0, stream, partial, nwg, rows_pad, ncols_pad, cin, m, dw);
     return erf_check_launch();
 }
 
-static void plan(long long P, int* nwg, int* spw) {
-    static const int target = getenv("ERF_WGRAD_WGS") ? atoi(getenv("ERF_WGRAD_WGS")) : 512;
+// Workgroups over the pixel range.  Each step is a short, latency-bound load -> LDS -> MFMA round, so small output tiles
+// (few KB of partial sums per workgroup) take up to 2048 workgroups for occupancy; large tiles stay at 512 so that the
+// partial sums the reduction reads back stay within ~24 MB.
+static void plan(long long P, size_t tile_bytes, int* nwg, int* spw) {
+    static const int forced = getenv("ERF_WGRAD_WGS") ? atoi(getenv("ERF_WGRAD_WGS")) : 0;
     static const int smin = getenv("ERF_WGRAD_SMIN") ? atoi(getenv("ERF_WGRAD_SMIN")) : 8;
+    long long target = forced;
+    if (target <= 0) {
+        target = (long long)((24u << 20) / (tile_bytes ? tile_bytes : 1));
+        target = target < 512 ? 512 : (target > 2048 ? 2048 : target);
+    }
     const long long steps = (P + 31) / 32;
     long long s = (steps + target - 1) / target;
     if (s < smin) s = smin;
@@ -221,9 +235,9 @@ static void plan(long long P, int* nwg, int* spw) {
 
 size_t wgrad_workspace_bytes(int rows, int cin, int max_taps_per_phase, long long base_pixels) {
     int nwg, spw;
-    plan(base_pixels, &nwg, &spw);
     const int rows_pad = (rows + 15) / 16 * 16;
     const int ncols_pad = (max_taps_per_phase * cin + 15) / 16 * 16;
+    plan(base_pixels, (size_t)rows_pad * ncols_pad * sizeof(float), &nwg, &spw);
     return (size_t)nwg * rows_pad * ncols_pad * sizeof(float);
 }
 
@@ -270,9 +284,11 @@ static int dispatch(const WgradParams& wp, int dtype, int cin, int cot, int cpw,
 int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, int rows, int cin, const PackParams* maps,
                  float* dw, float* workspace, size_t workspace_bytes, int dtype, hipStream_t stream) {
     const long long P = (long long)geo.N * geo.Hb * geo.Wb;
-    int nwg, spw;
-    plan(P, &nwg, &spw);
     const int cot = (rows + 15) / 16;
+    int max_taps = 1;
+    for (int ph = 0; ph < geo.nphase; ++ph) max_taps = geo.ph[ph].ntaps > max_taps ? geo.ph[ph].ntaps : max_taps;
+    int nwg, spw;                       // same plan as wgrad_workspace_bytes (the caller sized the workspace with it)
+    plan(P, (size_t)cot * 16 * ((max_taps * cin + 15) / 16 * 16) * sizeof(float), &nwg, &spw);
     const int epc = dtype == 1 ? 8 : 4;
     if (cin % epc) return ERF_EUNSUPPORTED;
     for (int ph = 0; ph < geo.nphase; ++ph) {
@@ -291,10 +307,7 @@ int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, in
         int rc = dispatch(wp, dtype, cin, cot, cpw, nwg, stream);
         if (rc) return rc;
         const PackParams& m = maps[ph];
-        const int total = m.cout_virtual * m.ntaps * cin;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, workspace, nwg, cot * 16,
-                           wp.ncols_pad, cin, m, dw);
-        rc = erf_check_launch();
+        rc = wgrad_reduce_launch(workspace, nwg, cot * 16, wp.ncols_pad, cin, m, dw, stream);
         if (rc) return rc;
     }
     return ERF_OK;
