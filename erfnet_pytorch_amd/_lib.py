@@ -104,6 +104,10 @@ SIGNATURES = {
     "erf_stem_wgrad": (I, [P, P, P, I, I, I, I, P, c_size_t, P]),
     "erf_upsampler_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
     "erf_output_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P]),
+    "erf_pack_desc_bytes": (c_size_t, []),
+    "erf_pack_record_begin": (I, [P, I]),
+    "erf_pack_record_end": (I, [P, P]),
+    "erf_pack_replay": (I, [P, I, ctypes.c_longlong, I, P]),
     "erf_conv3x3_packed_bytes": (c_size_t, [I, I, I]),
     "erf_conv3x3_pack": (I, [P, P, I, I, I, I, P]),
     "erf_conv3x3": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),

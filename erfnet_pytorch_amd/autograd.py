@@ -36,6 +36,13 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
+def _pack_now(fn, w, code, dev, *shape):
+    """Pack a sampler / head weight on the spot (no current PackedBank): `fn`_packed_bytes + `fn`_pack."""
+    pk = torch.empty(query(fn + "_packed_bytes", code, *shape), dtype=torch.uint8, device=dev)
+    call(fn + "_pack", _f32(w).data_ptr(), pk.data_ptr(), code, *shape, _stream())
+    return pk
+
+
 # --------------------------------------------------------------------------- primitive wrappers
 def bn_forward_stats(z, bn, training):
     """Returns (mean, invstd, scale, beta) for y = (z - mean)*scale + beta, scale = gamma*invstd; updates the
@@ -355,7 +362,8 @@ class _DownFn(torch.autograd.Function):
             xh = img
         else:
             xh = ops.to_nhwc(x)
-            z = ops.downsampler(xh, ops.pack_downsampler(w, code), None, shift, cout, relu=False)
+            z = ops.downsampler(xh, ops.packed_generic(mod, "fwd", w, code, lambda: ops.pack_downsampler(w, code)), None, shift, cout,
+                                relu=False)
         mean, invstd, s, t = bn_forward_stats(z, mod.bn, mod.training)
         out = bn_apply(z, mean, s, t)
         ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
@@ -400,8 +408,8 @@ class _DownFn(torch.autograd.Function):
              ws.data_ptr(), nb, _stream())
         dx = None
         if ctx.need_dx:
-            pk = torch.empty(query("erf_downsampler_dgrad_packed_bytes", code, cin, cout), dtype=torch.uint8, device=dev)
-            call("erf_downsampler_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, cin, cout, _stream())
+            pk = ops.packed_generic(ctx.mod, "dgrad", w, code,
+                                    lambda: _pack_now("erf_downsampler_dgrad", w, code, dev, cin, cout))
             dxh = torch.empty_like(xh)
             call("erf_downsampler_dgrad", dz.data_ptr(), dxh.data_ptr(), pk.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
                  _stream())
@@ -417,7 +425,8 @@ class _UpFn(torch.autograd.Function):
     def forward(ctx, x, mod, w, b, gamma, beta):
         xh = ops.to_nhwc(x)
         code = ops.dt(xh)
-        z = ops.upsampler(xh, ops.pack_upsampler(w, code), None, _f32(b), mod.noutput, relu=False)
+        z = ops.upsampler(xh, ops.packed_generic(mod, "fwd", w, code, lambda: ops.pack_upsampler(w, code)), None, _f32(b), mod.noutput,
+                          relu=False)
         mean, invstd, s, t = bn_forward_stats(z, mod.bn, mod.training)
         out = bn_apply(z, mean, s, t)
         ctx.save_for_backward(xh, z, out, mean, invstd, w, gamma)
@@ -444,8 +453,7 @@ class _UpFn(torch.autograd.Function):
         ws = _ws(nb, dev)
         call("erf_upsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, cout, ws.data_ptr(), nb,
              _stream())
-        pk = torch.empty(query("erf_upsampler_dgrad_packed_bytes", code, cin, cout), dtype=torch.uint8, device=dev)
-        call("erf_upsampler_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, cin, cout, _stream())
+        pk = ops.packed_generic(ctx.mod, "dgrad", w, code, lambda: _pack_now("erf_upsampler_dgrad", w, code, dev, cin, cout))
         dxh = torch.empty_like(xh)
         call("erf_upsampler_dgrad", dz.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, cin, cout, _stream())
         return (ops.to_nchw_view(dxh), None) + sk.ret(dw, db, dgamma, dbeta)
@@ -458,7 +466,8 @@ class _OutConvFn(torch.autograd.Function):
         xh = ops.to_nhwc(x)
         code = ops.dt(xh)
         nc = w.shape[1]
-        logits, _ = ops.output_conv(xh, ops.pack_output_conv(w, code), _f32(b), nc, True, logits_f32, False)
+        logits, _ = ops.output_conv(xh, ops.packed_generic(mod, "fwd", w, code, lambda: ops.pack_output_conv(w, code)), _f32(b), nc,
+                                    True, logits_f32, False)
         ctx.save_for_backward(xh, w)
         ctx.mod = mod
         return logits
@@ -481,8 +490,7 @@ class _OutConvFn(torch.autograd.Function):
         ws = _ws(nb, dev)
         call("erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc, ws.data_ptr(), nb,
              _stream())
-        pk = torch.empty(query("erf_output_conv_dgrad_packed_bytes", code, nc), dtype=torch.uint8, device=dev)
-        call("erf_output_conv_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, nc, _stream())
+        pk = ops.packed_generic(ctx.mod, "dgrad", w, code, lambda: _pack_now("erf_output_conv_dgrad", w, code, dev, nc))
         dxh = torch.empty_like(xh)
         call("erf_output_conv_dgrad", patches.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, nc, _stream())
         return (ops.to_nchw_view(dxh),) + sk.ret(dw, db) + (None, None)
@@ -497,7 +505,8 @@ class _PointwiseFn(torch.autograd.Function):
         xh = ops.to_nhwc(x)
         code = ops.dt(xh)
         nc = w.shape[0]
-        logits = ops.pointwise(xh, ops.pack_pointwise(w.flatten(1), code), _f32(b), nc, out_f32=logits_f32)
+        logits = ops.pointwise(xh, ops.packed_generic(mod, "fwd", w, code, lambda: ops.pack_pointwise(w.flatten(1), code)), _f32(b), nc,
+                               out_f32=logits_f32)
         ctx.save_for_backward(xh, w)
         ctx.mod = mod
         return logits
@@ -520,8 +529,7 @@ class _PointwiseFn(torch.autograd.Function):
         ws = _ws(nb, dev)
         call("erf_pointwise_wgrad", xh.data_ptr(), g.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, nc, ws.data_ptr(), nb,
              _stream())
-        pk = torch.empty(query("erf_pointwise_dgrad_packed_bytes", code, cin, nc), dtype=torch.uint8, device=dev)
-        call("erf_pointwise_dgrad_pack", _f32(w).data_ptr(), pk.data_ptr(), code, cin, nc, _stream())
+        pk = ops.packed_generic(ctx.mod, "dgrad", w, code, lambda: _pack_now("erf_pointwise_dgrad", w, code, dev, cin, nc))
         dxh = torch.empty_like(xh)
         call("erf_pointwise_dgrad", g.data_ptr(), dxh.data_ptr(), pk.data_ptr(), code, n, h, wd, cin, nc, _stream())
         return (ops.to_nchw_view(dxh),) + sk.ret(dw, db) + (None, None)

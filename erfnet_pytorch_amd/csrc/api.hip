@@ -317,6 +317,17 @@ int erf_image_to_nhwc_channels(const void* x_nchw, int x_dtype, void* out, int d
     return image_pad_launch(x_nchw, x_dtype, out, dtype, N, (long long)H * W, cpad, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------ batched weight re-packing
+size_t erf_pack_desc_bytes(void) { return sizeof(PackParams); }
+
+int erf_pack_record_begin(void* host_table, int capacity) { return pack_record_begin(host_table, capacity); }
+
+int erf_pack_record_end(long long* max_chunks, int* dtype) { return pack_record_end(max_chunks, dtype); }
+
+int erf_pack_replay(const void* table_dev, int count, long long max_chunks, int dtype, void* stream) {
+    return pack_replay_launch(table_dev, count, max_chunks, dtype, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ layout glue and metrics
 int erf_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, int H, int W, void* stream) {
     if (!src || !dst || !dtype_ok(src_dtype) || !dtype_ok(dst_dtype) || N <= 0 || C <= 0 || H <= 0 || W <= 0) return ERF_EINVAL;

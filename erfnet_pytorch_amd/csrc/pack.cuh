@@ -17,4 +17,7 @@ struct PackParams {
 };
 
 int pack_launch(const PackParams& p, int dtype, hipStream_t stream);
+int pack_record_begin(void* host_table, int capacity);
+int pack_record_end(long long* max_chunks, int* dtype);
+int pack_replay_launch(const void* table_dev, int count, long long max_chunks, int dtype, hipStream_t stream);
 int pack1d_many_launch(const long long* table, int count, int max_c, int dtype, hipStream_t stream);

@@ -102,6 +102,55 @@ class PackedBank:
             mod.__dict__["_erf_packed_bank"] = (self, bank)
         self.count = len(self._entries)
         self._sig, self.table = None, None
+        # the other layers (samplers, the two heads): (weight, buffer, pack entry point, its shape arguments);
+        # their re-packs are recorded once and replayed by one launch per refresh (erf_pack_replay)
+        self._generic = []
+        for mod in model.modules():
+            kinds = None
+            if isinstance(mod, E.DownsamplerBlock) and mod.ninput != 3:
+                kinds = {"fwd": ("erf_downsampler", (mod.ninput, mod.noutput)), "dgrad": ("erf_downsampler_dgrad", (mod.ninput, mod.noutput))}
+                w = mod.conv.weight
+            elif isinstance(mod, E.UpsamplerBlock):
+                kinds = {"fwd": ("erf_upsampler", (mod.ninput, mod.noutput)), "dgrad": ("erf_upsampler_dgrad", (mod.ninput, mod.noutput))}
+                w = mod.conv.weight
+            elif isinstance(mod, E.Decoder):
+                oc = mod.output_conv
+                kinds = {"fwd": ("erf_output_conv", (oc.out_channels,)), "dgrad": ("erf_output_conv_dgrad", (oc.out_channels,))}
+                w, mod = oc.weight, oc
+            elif isinstance(mod, E.Encoder):
+                oc = mod.output_conv
+                kinds = {"fwd": ("erf_pointwise", (oc.in_channels, oc.out_channels)), "dgrad": ("erf_pointwise_dgrad", (oc.in_channels, oc.out_channels))}
+                w, mod = oc.weight, oc
+            if kinds is None:
+                continue
+            bufs = {}
+            for kind, (fn, shape) in kinds.items():
+                nbytes = query(fn + "_packed_bytes", code, *shape)
+                if nbytes <= 0:
+                    continue
+                buf = _packed(nbytes, dev)
+                bufs[kind] = buf
+                self._generic.append((w, buf, fn + "_pack", shape))
+            mod.__dict__["_erf_packed_generic"] = (self, bufs, w)
+        self._gsig, self._gtable, self._gcount, self._gmax = None, None, 0, 0
+
+    def _record_generic(self):
+        import ctypes
+        desc = query("erf_pack_desc_bytes")
+        cap = 8 * len(self._generic)                         # an entry point may issue several re-packs (one per phase)
+        host = torch.zeros(cap * desc, dtype=torch.uint8)
+        out = torch.zeros(2, dtype=torch.int64)
+        dt_out = torch.zeros(1, dtype=torch.int32)
+        call("erf_pack_record_begin", host.data_ptr(), cap)
+        try:
+            for (w, buf, fn, shape) in self._generic:
+                call(fn, w.data_ptr(), buf.data_ptr(), self.code, *shape, _stream())
+        finally:
+            n = query("erf_pack_record_end", out.data_ptr(), dt_out.data_ptr())
+        if n < 0:
+            raise _lib.ErfError(f"recording the weight re-packs failed with status {n}")
+        self._gcount, self._gmax = int(n), int(out[0])
+        self._gtable = host[: n * desc].to(self._generic[0][1].device) if n else None
 
     def refresh(self):
         sig = tuple(w.data_ptr() for (w, _b, _c, _m) in self._entries)
@@ -111,7 +160,24 @@ class PackedBank:
             self._sig = sig
         if self.count:
             call("erf_conv1d_pack_many", self.table.data_ptr(), self.count, self.max_c, self.code, _stream())
+        gsig = tuple(w.data_ptr() for (w, _b, _f, _s) in self._generic)
+        if gsig != self._gsig and self._generic:
+            self._record_generic()
+            self._gsig = gsig
+        if self._gcount:
+            call("erf_pack_replay", self._gtable.data_ptr(), self._gcount, self._gmax, self.code, _stream())
         self.epoch = PARAM_EPOCH[0]
+
+
+def packed_generic(mod, kind: str, w: torch.Tensor, code: int, pack_now):
+    """Packed weights of a sampler / head layer: from the model's PackedBank when it is current, else `pack_now()`."""
+    ent = mod.__dict__.get("_erf_packed_generic") if mod is not None else None
+    if ent is not None:
+        bank, bufs, wp = ent
+        if bank.code == code and bank.epoch == PARAM_EPOCH[0] and kind in bufs and wp.data_ptr() == w.data_ptr() \
+                and w.dtype == torch.float32:
+            return bufs[kind]
+    return pack_now()
 
 
 def packed_conv1d(mod, name: str, w: torch.Tensor, code: int, mode: int = 0) -> torch.Tensor:

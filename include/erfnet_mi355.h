@@ -185,6 +185,17 @@ int erf_adam_fused_arena(float* params, const float* grads, float* exp_avg, floa
 int erf_sgd_fused_arena(float* params, const float* grads, float* momentum_buf, long long n, double lr, double momentum,
                         double weight_decay, int first_step, double grad_scale, void* stream);
 
+/* ---- batched weight re-packing (no counterpart in the reference: torch re-reads the fp32 parameters in place) ----
+ * A training step re-packs every weight after the optimiser update.  Between erf_pack_record_begin(host_table,
+ * capacity) and erf_pack_record_end the *_pack calls of the calling thread launch nothing: each appends one or more
+ * descriptors (erf_pack_desc_bytes() bytes each, holding the source and destination pointers passed) to host_table.
+ * erf_pack_record_end returns the number of descriptors (or a negative status) and the grid extent / dtype to pass on.
+ * The caller copies the table to device memory once; erf_pack_replay then redoes all those re-packs in one launch. */
+size_t erf_pack_desc_bytes(void);
+int erf_pack_record_begin(void* host_table, int capacity);
+int erf_pack_record_end(long long* max_chunks, int* dtype);
+int erf_pack_replay(const void* table_dev, int count, long long max_chunks, int dtype, void* stream);
+
 /* ---- Multi_models (train/multi_models.py), inference -------------------------------------------------------
  * The multi-task network reuses non_bottleneck_1d and UpsamplerBlock (also 128 -> 16, multi_models.py:127) and adds:
  * erf_conv3x3: 3x3 convolution, padding 1, stride 1 or 2, y = act(scale * conv(x) + shift), NHWC in and out
