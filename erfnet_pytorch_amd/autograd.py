@@ -36,6 +36,17 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
+def _count_batch(bn):
+    """`num_batches_tracked += 1` of a BatchNorm forward in training mode; a trainer that owns the model may take the
+    39 one-element updates over (it sets `_erf_batch_counter` to a list the layer is appended to, and adds 1 to all of
+    them with one multi-tensor call per step)."""
+    pending = bn.__dict__.get("_erf_batch_counter")
+    if pending is not None:
+        pending.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
 def _pack_now(fn, w, code, dev, *shape):
     """Pack a sampler / head weight on the spot (no current PackedBank): `fn`_packed_bytes + `fn`_pack."""
     pk = torch.empty(query(fn + "_packed_bytes", code, *shape), dtype=torch.uint8, device=dev)
@@ -62,7 +73,7 @@ def bn_forward_stats(z, bn, training):
              _p(bn.running_mean if track else None), _p(bn.running_var if track else None), momentum, bn.eps,
              mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream())
         if track:
-            bn.num_batches_tracked += 1
+            _count_batch(bn)
         return mean, invstd, scale, beta
     invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
     scale = gamma * invstd
@@ -88,7 +99,7 @@ def conv1d_bn_stats(x, packed, bias, axis, dilation, bn, training):
                    scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream())
         if rc == 0:
             if track:
-                bn.num_batches_tracked += 1
+                _count_batch(bn)
             return z, mean, invstd, scale, beta
         if rc != -2:
             raise RuntimeError(f"erf_conv1d_factorized_bn failed with status {rc}")

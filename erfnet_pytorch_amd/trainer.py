@@ -43,6 +43,21 @@ def poly_lr(base_lr, epoch, num_epochs):
     return base_lr * math.pow(1 - ((epoch - 1) / num_epochs), 0.9)
 
 
+def _take_over_batch_counters(model):
+    """BatchNorm layers append their num_batches_tracked to the returned list instead of launching one add each."""
+    pending = []
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.__dict__["_erf_batch_counter"] = pending
+    return pending
+
+
+def _flush_batch_counters(pending):
+    if pending:
+        torch._foreach_add_(list(pending), 1)
+        pending.clear()
+
+
 def _refresh_bank(bank, model, images):
     """(Re)build the model's PackedBank for the step's compute dtype and re-pack every factorized-conv weight."""
     from . import ops
@@ -101,6 +116,7 @@ class Trainer:
             mod.__dict__["_erf_grad_sink_zeroed"] = True    # step() clears the arena before every backward pass
 
         self._bank = None                               # packed factorized-conv weights, refreshed once per step
+        self._counted = _take_over_batch_counters(model)
         # all-reduce buckets (backward-completion order) and the ranges Adam may touch
         self.buckets, self.active = dp.bucket_ranges(self.offsets, only_encode)
         self._pending = []
@@ -141,6 +157,7 @@ class Trainer:
         self.zero_grad()                                              # optimizer.zero_grad(), train/main.py:200
         self._refresh_packed(images)
         outputs = self.model(images, only_encode=True) if self.only_encode else self.model(images)
+        _flush_batch_counters(self._counted)
         loss = weighted_cross_entropy(outputs, targets, self.weight, self.group if self.world > 1 else None)
         loss.backward()
         self._reduce_gradients()
