@@ -107,12 +107,45 @@ def conv1d_bn_stats(x, packed, bias, axis, dilation, bn, training):
     return (z,) + tuple(bn_forward_stats(z, bn, training))
 
 
-def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=None):
-    """dx = conv1d_dgrad(...) and the bias gradient sum_p dx[p][c] of the convolution that produced dx's tensor."""
+# Bias gradients are leaves of the backward pass: their last step (summing the per-workgroup partial rows) is put off
+# and done for all of them by one launch -- when a block hands gradients back to autograd, before a gradient bucket is
+# all-reduced, or when the trainer calls flush_bias_sums() after backward.
+# (The backward pass runs on autograd's device thread, the trainer on the caller's: the list is shared, per device.)
+_PENDING_SUMS = {}
+_PENDING_LOCK = threading.Lock()
+
+
+def flush_bias_sums():
+    with _PENDING_LOCK:
+        todo = [(dev, ent) for dev, ent in _PENDING_SUMS.items() if ent[0]]
+        for dev, _ in todo:
+            _PENDING_SUMS[dev] = ([], [])
+    for dev, (rows, _keep) in todo:
+        table = torch.tensor(rows, dtype=torch.int64)
+        with torch.cuda.device(dev):
+            call("erf_channel_sum_finalize_many", table.data_ptr(), len(rows), _stream())
+
+
+def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=None, defer=False):
+    """dx = conv1d_dgrad(...) and the bias gradient sum_p dx[p][c] of the convolution that produced dx's tensor.
+    defer: the sum is complete only after flush_bias_sums()."""
     n, h, w, c = dy.shape
     dx = torch.empty_like(dy)
     db = torch.empty(c, device=dy.device) if dbias_out is None else dbias_out
     ws = _ws(query("erf_bn_workspace_bytes", c), dy.device)
+    if defer:
+        rc = query("erf_conv1d_dgrad_bias_partial", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), _p(gate), _p(residual),
+                   ops.dt(dy), n, h, w, c, axis, dilation, ws.data_ptr(), _stream())
+        if rc > 0:
+            with _PENDING_LOCK:
+                rows, keep = _PENDING_SUMS.setdefault(dy.device.index, ([], []))
+                rows.append([ws.data_ptr(), rc, c, db.data_ptr()])
+                keep.append((ws, db))                    # alive until the flush has enqueued the kernel that reads them
+            return dx, db
+        if rc != -2:
+            raise RuntimeError(f"erf_conv1d_dgrad_bias_partial failed with status {rc}")
+        dx = conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation)
+        return dx, channel_sum(dx, db)
     rc = query("erf_conv1d_dgrad_bias", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), _p(gate), _p(residual), ops.dt(dy), n, h, w,
                c, axis, dilation, db.data_ptr(), ws.data_ptr(), _stream())
     if rc == 0:
@@ -261,7 +294,8 @@ class _Sink:
     torch optimisers work).  When a trainer attached `_erf_grad_sink` (parameter name -> view of its
     flat fp32 gradient arena) to the module, the kernels write straight into the arena, autograd gets
     None for those parameters, and `_erf_after_backward` (if set) is called once the block's gradients
-    are enqueued -- the hook gradient-bucket all-reduces hang on."""
+    are enqueued -- the hook gradient-bucket all-reduces hang on.  An owner of a sink calls flush_bias_sums()
+    after backward(): the convolution-bias gradients are complete only then."""
 
     def __init__(self, mod):
         self.views = mod.__dict__.get("_erf_grad_sink") if mod is not None else None
@@ -277,8 +311,10 @@ class _Sink:
     def ret(self, *grads):
         if self.views is not None:
             if self.after is not None:
+                flush_bias_sums()                        # the bucket all-reduce reads the bias gradients
                 self.after()
             return tuple(None for _ in grads)
+        flush_bias_sums()                                # autograd consumes the gradients
         return grads
 
 
@@ -328,7 +364,7 @@ class _NB1dFn(torch.autograd.Function):
         db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)), sk.zeroed)
         dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
         dz3, db3 = conv1d_dgrad_bias(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d,
-                                     o("conv3x1_2.bias", (c,)))
+                                     o("conv3x1_2.bias", (c,)), defer=True)
         dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape))
         fused = conv1d_dgrad_bn_backward(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), a2, None, AXIS_H, d, z2,
                                          mean1, invstd1, _f32(g1), None, ctx.training, o("bn1.weight", (c,)),
@@ -342,7 +378,7 @@ class _NB1dFn(torch.autograd.Function):
         db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)), sk.zeroed)
         dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
         dz1, db1 = conv1d_dgrad_bias(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1,
-                                     o("conv3x1_1.bias", (c,)))
+                                     o("conv3x1_1.bias", (c,)), defer=True)
         dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape))
         t, fused = ctx.tail, None
         if t is not None:                     # this block's input is the ReLU output of a BatchNorm: run that layer's backward here

@@ -142,6 +142,35 @@ int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t,
                                (hipStream_t)stream);
 }
 
+// erf_conv1d_dgrad_bias without its last step: the partial rows stay in `workspace` (the return value is their number,
+// > 0) and erf_channel_sum_finalize_many later turns the partial rows of many such calls into their sums in one launch.
+int erf_conv1d_dgrad_bias_partial(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual,
+                                  int dtype, int N, int H, int W, int C, int axis, int dilation, void* workspace, void* stream) {
+    if (!dy || !dx || !packed_t || !workspace || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || dilation < 1) return ERF_EINVAL;
+    if (C != 16 && C != 64 && C != 128) return ERF_EUNSUPPORTED;
+    int groups = 0;
+    const int rc = conv1d_buf_launch(dy, dx, packed_t, nullptr, nullptr, residual, gate, (double*)workspace, &groups, dtype, N, H, W,
+                                     C, axis, dilation, 0, (hipStream_t)stream);
+    return rc ? rc : groups;
+}
+
+// table: count rows of {workspace pointer, number of partial rows, C, destination pointer (C floats)} in HOST memory
+int erf_channel_sum_finalize_many(const long long* table, int count, void* stream) {
+    if (!table || count <= 0) return ERF_EINVAL;
+    for (int base = 0; base < count; base += ERF_CHANNEL_SUM_MAX) {
+        ChannelSumTable t{};
+        t.count = count - base < ERF_CHANNEL_SUM_MAX ? count - base : ERF_CHANNEL_SUM_MAX;
+        for (int i = 0; i < t.count; ++i) {
+            const long long* r = table + 4 * (long long)(base + i);
+            if (!r[0] || !r[3] || r[1] <= 0 || r[2] <= 0) return ERF_EINVAL;
+            t.e[i].partials = (const double*)r[0]; t.e[i].groups = (int)r[1]; t.e[i].C = (int)r[2]; t.e[i].sums = (float*)r[3];
+        }
+        const int rc = channel_sum_finalize_many_launch(t, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ERF_OK;
+}
+
 int erf_dropout2d_mask(float* mask, int count, float p, unsigned long long seed, void* stream) {
     if (!mask) return ERF_EINVAL;
     return dropout_mask_launch(mask, count, p, seed, (hipStream_t)stream);

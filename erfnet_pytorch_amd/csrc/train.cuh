@@ -7,6 +7,10 @@
 size_t bn_workspace_bytes(int C);
 float* bn_workspace_coef(void* workspace, int C);
 int channel_sum_finalize_launch(const float* partials, int groups, int C, float* sums, hipStream_t stream);
+#define ERF_CHANNEL_SUM_MAX 48
+struct ChannelSumEntry { const double* partials; float* sums; int groups, C; };
+struct ChannelSumTable { ChannelSumEntry e[ERF_CHANNEL_SUM_MAX]; int count; };
+int channel_sum_finalize_many_launch(const ChannelSumTable& t, hipStream_t stream);
 int bn_stats_launch(const void* z, int dtype, long long P, int C, float* partials, int* groups, hipStream_t stream);
 int bn_finalize_launch(const float* partials, int groups, int C, long long count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,

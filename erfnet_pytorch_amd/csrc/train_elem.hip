@@ -139,6 +139,25 @@ __global__ void channel_sum_finalize_kernel(const double* __restrict__ partials,
     if (threadIdx.x < FIN_CB && c < C) sums[c] = (float)s;
 }
 
+// Many channel sums in one launch: blockIdx.y = entry, blockIdx.x = channel block of that entry (entries with fewer
+// channels leave their extra blocks idle).  The table travels as a kernel argument.
+__global__ void channel_sum_finalize_many_kernel(const ChannelSumTable t) {
+    const ChannelSumEntry& e = t.e[blockIdx.y];
+    if ((int)blockIdx.x * FIN_CB >= e.C) return;
+    double s, ss;
+    reduce_partials(e.partials, e.groups, e.C, s, ss);
+    const int c = blockIdx.x * FIN_CB + threadIdx.x;
+    if (threadIdx.x < FIN_CB && c < e.C) e.sums[c] = (float)s;
+}
+
+int channel_sum_finalize_many_launch(const ChannelSumTable& t, hipStream_t stream) {
+    if (t.count <= 0 || t.count > ERF_CHANNEL_SUM_MAX) return ERF_EINVAL;
+    int maxc = 0;
+    for (int i = 0; i < t.count; ++i) maxc = t.e[i].C > maxc ? t.e[i].C : maxc;
+    hipLaunchKernelGGL(channel_sum_finalize_many_kernel, dim3(fin_blocks(maxc), t.count), dim3(FIN_THREADS), 0, stream, t);
+    return erf_check_launch();
+}
+
 int channel_sum_finalize_launch(const float* partials, int groups, int C, float* sums, hipStream_t stream) {
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(fin_blocks(C)), dim3(FIN_THREADS), 0, stream, (const double*)partials, groups, C, sums);
     return erf_check_launch();

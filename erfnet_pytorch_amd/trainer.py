@@ -24,6 +24,7 @@ import time
 
 import torch
 
+from . import autograd as ag
 from . import dp
 from . import erfnet as E
 from ._lib import call
@@ -160,6 +161,7 @@ class Trainer:
         _flush_batch_counters(self._counted)
         loss = weighted_cross_entropy(outputs, targets, self.weight, self.group if self.world > 1 else None)
         loss.backward()
+        ag.flush_bias_sums()
         self._reduce_gradients()
         self.optimizer_step()
         return loss.detach(), outputs.detach()
@@ -277,6 +279,7 @@ class ArenaSGD:
         outputs = self.model(images)
         loss = weighted_cross_entropy(outputs, targets, None, self.group if self.world > 1 else None)
         loss.backward()
+        ag.flush_bias_sums()
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.gflat, group=self.group)

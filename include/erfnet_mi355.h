@@ -299,6 +299,13 @@ int erf_conv1d_factorized_bn(const void* x, void* z, const void* packed, const f
                              float* shift, void* workspace, void* stream);
 int erf_conv1d_dgrad_bias(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual, int dtype,
                           int N, int H, int W, int C, int axis, int dilation, float* dbias, void* workspace, void* stream);
+/* erf_conv1d_dgrad_bias in two parts, so that the bias gradients of a whole backward pass are finished by one launch:
+ * erf_conv1d_dgrad_bias_partial leaves the partial rows in `workspace` (erf_bn_workspace_bytes(C)) and returns their
+ * number (> 0; negative: status); erf_channel_sum_finalize_many(table, count) takes `count` rows of
+ * {workspace pointer, partial rows, C, destination pointer} (int64, host memory) and writes every sum. */
+int erf_conv1d_dgrad_bias_partial(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual,
+                                  int dtype, int N, int H, int W, int C, int axis, int dilation, void* workspace, void* stream);
+int erf_channel_sum_finalize_many(const long long* table, int count, void* stream);
 int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual,
                                  int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
                                  const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
