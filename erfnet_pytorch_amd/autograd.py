@@ -107,11 +107,12 @@ def conv1d_bn_stats(x, packed, bias, axis, dilation, bn, training):
     return (z,) + tuple(bn_forward_stats(z, bn, training))
 
 
-# Bias gradients are leaves of the backward pass: their last step (summing the per-workgroup partial rows) is put off
-# and done for all of them by one launch -- when a block hands gradients back to autograd, before a gradient bucket is
-# all-reduced, or when the trainer calls flush_bias_sums() after backward.
-# (The backward pass runs on autograd's device thread, the trainer on the caller's: the list is shared, per device.)
+# Bias and weight gradients are leaves of the backward pass: their last step (summing per-workgroup partial results) is
+# put off and done for all of them by one launch each -- when a block hands gradients back to autograd, before a
+# gradient bucket is all-reduced, or when the trainer calls flush_bias_sums() after backward.
+# (The backward pass runs on autograd's device thread, the trainer on the caller's: the lists are shared, per device.)
 _PENDING_SUMS = {}
+_PENDING_WGRAD = {}
 _PENDING_LOCK = threading.Lock()
 
 
@@ -120,10 +121,17 @@ def flush_bias_sums():
         todo = [(dev, ent) for dev, ent in _PENDING_SUMS.items() if ent[0]]
         for dev, _ in todo:
             _PENDING_SUMS[dev] = ([], [])
+        wtodo = [(dev, ent) for dev, ent in _PENDING_WGRAD.items() if ent]
+        for dev, _ in wtodo:
+            _PENDING_WGRAD[dev] = []
     for dev, (rows, _keep) in todo:
         table = torch.tensor(rows, dtype=torch.int64)
         with torch.cuda.device(dev):
             call("erf_channel_sum_finalize_many", table.data_ptr(), len(rows), _stream())
+    for dev, ents in wtodo:
+        with torch.cuda.device(dev):
+            table = torch.cat([e[0] for e in ents]).to(torch.device("cuda", dev), non_blocking=False)
+            call("erf_wgrad_reduce_many", table.data_ptr(), len(ents), max(e[1] for e in ents), _stream())
 
 
 def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=None, defer=False):
@@ -269,8 +277,19 @@ def conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation):
     return dx
 
 
-def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None):
+def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None, defer=False):
+    """dW of a factorized convolution.  defer: only the contraction is launched; dW is complete after flush_bias_sums()."""
     n, h, w, c = x.shape
+    if defer:
+        dw = torch.empty(wshape, device=x.device) if out is None else out
+        nb = query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
+        ws = _ws(nb, x.device)
+        desc = torch.zeros(query("erf_wgrad_reduce_desc_bytes"), dtype=torch.uint8)
+        call("erf_conv1d_wgrad_partial", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ops.dt(x), n, h, w, c, axis, dilation,
+             ws.data_ptr(), nb, desc.data_ptr(), _stream())
+        with _PENDING_LOCK:
+            _PENDING_WGRAD.setdefault(x.device.index, []).append((desc, 3 * c * c, ws, dw))
+        return dw
     dw = torch.empty(wshape, device=x.device) if out is None else out
     nb = query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
     ws = _ws(nb, x.device)
@@ -362,10 +381,10 @@ class _NB1dFn(torch.autograd.Function):
             dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True,
                                                 dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
         db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)), sk.zeroed)
-        dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape))
+        dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape), defer=True)
         dz3, db3 = conv1d_dgrad_bias(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d,
                                      o("conv3x1_2.bias", (c,)), defer=True)
-        dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape))
+        dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape), defer=True)
         fused = conv1d_dgrad_bn_backward(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), a2, None, AXIS_H, d, z2,
                                          mean1, invstd1, _f32(g1), None, ctx.training, o("bn1.weight", (c,)),
                                          o("bn1.bias", (c,))) if FUSE_BN_BACKWARD else None
@@ -376,10 +395,10 @@ class _NB1dFn(torch.autograd.Function):
             dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
                                             dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
         db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)), sk.zeroed)
-        dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape))
+        dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape), defer=True)
         dz1, db1 = conv1d_dgrad_bias(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1,
                                      o("conv3x1_1.bias", (c,)), defer=True)
-        dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape))
+        dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape), defer=True)
         t, fused = ctx.tail, None
         if t is not None:                     # this block's input is the ReLU output of a BatchNorm: run that layer's backward here
             psk = _Sink(t.mod)

@@ -418,6 +418,26 @@ int erf_conv1d_wgrad(const void* x, const void* dz, float* dw, int dtype, int N,
     return wgrad_launch(g, dz, C, 0, C, C, &m, dw, (float*)workspace, workspace_bytes, dtype, (hipStream_t)stream);
 }
 
+// erf_conv1d_wgrad without its last step: the per-workgroup partial tiles stay in `workspace` (which must stay untouched)
+// and `desc` (host memory, erf_wgrad_reduce_desc_bytes()) receives the arguments of the pending reduction.
+size_t erf_wgrad_reduce_desc_bytes(void) { return sizeof(WgradReduceDesc); }
+
+int erf_conv1d_wgrad_partial(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis,
+                             int dilation, void* workspace, size_t workspace_bytes, void* desc, void* stream) {
+    if (!desc) return ERF_EINVAL;
+    WgradReduceDesc* d = (WgradReduceDesc*)desc;
+    d->partial = nullptr;
+    wgrad_reduce_defer(d);
+    const int rc = erf_conv1d_wgrad(x, dz, dw, dtype, N, H, W, C, axis, dilation, workspace, workspace_bytes, stream);
+    wgrad_reduce_defer(nullptr);
+    if (rc) return rc;
+    return d->partial ? ERF_OK : ERF_ELAUNCH;           // the contraction must have reached (and deferred) its reduction
+}
+
+int erf_wgrad_reduce_many(const void* table_dev, int count, int max_total, void* stream) {
+    return wgrad_reduce_many_launch(table_dev, count, max_total, (hipStream_t)stream);
+}
+
 int erf_downsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, int N, int Hin, int Win, int Cin, int Cout,
                           void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !dz || !dw || !workspace || !dtype_ok(dtype) || N <= 0 || ((Hin | Win) & 1)) return ERF_EINVAL;

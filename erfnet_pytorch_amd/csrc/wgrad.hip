@@ -205,8 +205,69 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The same reduction for a table of descriptors (device memory): blockIdx.y = entry, blockIdx.x = block of 32 elements.
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const WgradReduceDesc* __restrict__ table) {
+    constexpr int E = 32, S = 8;
+    __shared__ double sh[S][E];
+    const WgradReduceDesc& d = table[blockIdx.y];
+    const PackParams& m = d.m;
+    const int total = m.cout_virtual * m.ntaps * d.cin;
+    if ((int)blockIdx.x * E >= total) return;
+    const int e = threadIdx.x % E, sl = threadIdx.x / E;
+    const int idx = blockIdx.x * E + e;
+    bool valid = idx < total;
+    int col = 0, row = 0, tap = 0, ci = 0, phase = 0, cls = 0;
+    if (valid) {
+        col = idx % (m.ntaps * d.cin); row = idx / (m.ntaps * d.cin);
+        tap = col / d.cin; ci = col % d.cin;
+        phase = row / m.ncp; cls = row % m.ncp;
+        valid = cls < m.nc_valid && !(m.cin_valid && ci >= m.cin_valid);
+    }
+    double acc = 0.0;
+    if (valid) {
+        const long long stride = (long long)d.rows_pad * d.ncols_pad;
+        const float* src = d.partial + (long long)row * d.ncols_pad + col;
+        const int per = (d.nwg + S - 1) / S;
+        int g = sl * per;
+        const int g1 = g + per < d.nwg ? g + per : d.nwg;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (; g + 4 <= g1; g += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += src[(g + u) * stride];
+        }
+        for (; g < g1; ++g) s4[0] += src[g * stride];
+        acc = ((double)s4[0] + (double)s4[1]) + ((double)s4[2] + (double)s4[3]);
+    }
+    sh[sl][e] = acc;
+    __syncthreads();
+    if (sl == 0 && valid) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) s += sh[k][e];
+        d.dw[(long long)cls * m.s_co + (long long)phase * m.s_phase + (long long)ci * m.s_ci + m.toff[tap]] = (float)s;
+    }
+}
+
+int wgrad_reduce_many_launch(const void* table_dev, int count, int max_total, hipStream_t stream) {
+    if (!table_dev || count <= 0 || max_total <= 0) return ERF_EINVAL;
+    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((max_total + 31) / 32, count), dim3(256), 0, stream,
+                       (const WgradReduceDesc*)table_dev);
+    return erf_check_launch();
+}
+
+// While a descriptor slot is set for the calling thread, the next reduction is not launched: its arguments are written
+// to the slot (host memory) for a later wgrad_reduce_many_launch.
+static thread_local WgradReduceDesc* t_reduce_slot = nullptr;
+void wgrad_reduce_defer(WgradReduceDesc* slot) { t_reduce_slot = slot; }
+
 int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_pad, int cin, const PackParams& m, float* dw,
                         hipStream_t stream) {
+    if (t_reduce_slot) {
+        WgradReduceDesc& d = *t_reduce_slot;
+        d.partial = partial; d.dw = dw; d.nwg = nwg; d.rows_pad = rows_pad; d.ncols_pad = ncols_pad; d.cin = cin; d.m = m;
+        t_reduce_slot = nullptr;
+        return ERF_OK;
+    }
     const int total = m.cout_virtual * m.ntaps * cin;
     if (nwg >= 1024)
         hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((total + 7) / 8), dim3(256), 0, stream, partial, nwg, rows_pad, ncols_pad, cin, m, dw);
