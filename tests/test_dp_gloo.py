@@ -80,7 +80,9 @@ def _worker(rank, world, port, q):
         for lo, hi in buckets:                      # decoder first, as the backward pass finishes them
             dist.all_reduce(arena[lo:hi])
         if rank == 0:
-            q.put({"loss": float(gnum / gden), "arena": arena, "names": names, "buckets": buckets, "active": active,
+            # plain numpy in the queue: a torch tensor travels as a file descriptor that the parent has to fetch from this
+            # process, which fails when the worker has already exited
+            q.put({"loss": float(gnum / gden), "arena": arena.numpy().copy(), "names": names, "buckets": buckets, "active": active,
                    "offsets": offsets})
     finally:
         dist.destroy_process_group()
@@ -115,6 +117,7 @@ def test_two_rank_step_equals_dataparallel_semantics():
     world = 2
     got = _run_world(world) or _run_world(world)             # one retry on a lost port race
     assert got is not None, "the two gloo ranks did not complete"
+    got["arena"] = torch.from_numpy(got["arena"])
 
     # single-process emulation of nn.DataParallel
     sd = _state()
