@@ -51,6 +51,9 @@ SIGNATURES = {
     "erf_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
     "erf_conv1d_factorized_bn": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, ctypes.c_float, ctypes.c_float, P, P, P, P, P, P]),
     "erf_conv1d_dgrad_bias": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "erf_output_conv_ce_workspace_bytes": (c_size_t, [I, I, I]),
+    "erf_output_conv_ce_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "erf_output_conv_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "erf_wgrad_reduce_desc_bytes": (c_size_t, []),
     "erf_conv1d_wgrad_partial": (I, [P, P, P, I, I, I, I, I, I, I, P, c_size_t, P, P]),
     "erf_wgrad_reduce_many": (I, [P, I, I, P]),

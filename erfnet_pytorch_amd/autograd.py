@@ -548,18 +548,66 @@ class _OutConvFn(torch.autograd.Function):
         ld = query("erf_output_conv_patch_channels", nc)
         patches = torch.empty((n, h, wd, ld), dtype=xh.dtype, device=dev)
         call("erf_output_conv_patches", glogits.data_ptr(), ops.dt(glogits), patches.data_ptr(), code, n, h, wd, nc, _stream())
-        sk = _Sink(ctx.mod)
-        db = sk.out("bias", (nc,), dev)
-        db.copy_(channel_sum(patches)[: 4 * nc].reshape(nc, 4).sum(1))
-        dw = sk.out("weight", w.shape, dev)
-        nb = query("erf_wgrad_workspace_bytes", 4 * nc, 16, 1, n * h * wd)
-        ws = _ws(nb, dev)
-        call("erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc, ws.data_ptr(), nb,
-             _stream())
-        pk = ops.packed_generic(ctx.mod, "dgrad", w, code, lambda: _pack_now("erf_output_conv_dgrad", w, code, dev, nc))
-        dxh = torch.empty_like(xh)
-        call("erf_output_conv_dgrad", patches.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, nc, _stream())
-        return (ops.to_nchw_view(dxh),) + sk.ret(dw, db) + (None, None)
+        return _outconv_backward(ctx.mod, xh, w, patches) + (None, None)
+
+
+def _outconv_backward(mod, xh, w, patches):
+    """Bias / weight / data gradients of Decoder.output_conv from the patch form of d logits.  Returns (dx, dw, db)."""
+    code, dev = ops.dt(xh), xh.device
+    n, h, wd, _ = xh.shape
+    nc = w.shape[1]
+    sk = _Sink(mod)
+    db = sk.out("bias", (nc,), dev)
+    db.copy_(channel_sum(patches)[: 4 * nc].reshape(nc, 4).sum(1))
+    dw = sk.out("weight", w.shape, dev)
+    nb = query("erf_wgrad_workspace_bytes", 4 * nc, 16, 1, n * h * wd)
+    ws = _ws(nb, dev)
+    call("erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc, ws.data_ptr(), nb,
+         _stream())
+    pk = ops.packed_generic(mod, "dgrad", w, code, lambda: _pack_now("erf_output_conv_dgrad", w, code, dev, nc))
+    dxh = torch.empty_like(xh)
+    call("erf_output_conv_dgrad", patches.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, nc, _stream())
+    return (ops.to_nchw_view(dxh),) + sk.ret(dw, db)
+
+
+class _HeadLossFn(torch.autograd.Function):
+    """Decoder.output_conv and the weighted cross entropy in one pass each way: the logits exist in registers only
+    (train/erfnet.py:171,179 + train/main.py:121,202).  Returns the loss  sum_p w[t_p] nll_p / sum_p w[t_p]  with both
+    sums taken over the process group when one is given, exactly as loss.weighted_cross_entropy does on stored logits."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, target, weight, group, mod):
+        from .dp import global_weighted_mean
+        xh = ops.to_nhwc(x)
+        code, dev = ops.dt(xh), xh.device
+        n, h, wd, _ = xh.shape
+        nc = w.shape[1]
+        target = target.contiguous()
+        if target.dtype != torch.int64 or tuple(target.shape) != (n, 2 * h, 2 * wd):
+            raise ValueError(f"expected int64 targets of shape {(n, 2 * h, 2 * wd)}, got {target.dtype} {tuple(target.shape)}")
+        wt = None if weight is None else weight.detach().to(dev, torch.float32).contiguous()
+        packed = ops.packed_generic(mod, "fwd", w, code, lambda: ops.pack_output_conv(w, code))
+        bias = _f32(b)
+        out3 = torch.empty(3, device=dev)
+        ws = _ws(query("erf_output_conv_ce_workspace_bytes", n, h, wd), dev)
+        call("erf_output_conv_ce_fwd", xh.data_ptr(), packed.data_ptr(), bias.data_ptr(), target.data_ptr(), _p(wt), out3.data_ptr(),
+             ws.data_ptr(), code, n, h, wd, nc, _stream())
+        num, den = global_weighted_mean(out3[0], out3[1], group)
+        ctx.save_for_backward(xh, w, bias, target, den.reshape(1), packed)
+        ctx.weight, ctx.mod = wt, mod
+        return num / den
+
+    @staticmethod
+    def backward(ctx, gout):
+        xh, w, bias, target, den, packed = ctx.saved_tensors
+        code, dev = ops.dt(xh), xh.device
+        n, h, wd, _ = xh.shape
+        nc = w.shape[1]
+        coef = (gout.reshape(1).float() / den).contiguous()
+        patches = torch.empty((n, h, wd, query("erf_output_conv_patch_channels", nc)), dtype=xh.dtype, device=dev)
+        call("erf_output_conv_ce_bwd", xh.data_ptr(), packed.data_ptr(), bias.data_ptr(), target.data_ptr(), _p(ctx.weight),
+             coef.data_ptr(), patches.data_ptr(), code, n, h, wd, nc, _stream())
+        return _outconv_backward(ctx.mod, xh, w, patches) + (None, None, None, None)
 
 
 # --------------------------------------------------------------------------- Encoder.output_conv (encoder-only training)
@@ -635,6 +683,17 @@ def decoder_forward(dec, x, logits_f32=True):
     for layer in dec.layers:
         y = block_forward(layer, y)
     return _OutConvFn.apply(y, dec.output_conv.weight, dec.output_conv.bias, logits_f32, dec.output_conv)
+
+
+def erfnet_forward_loss(net, x, target, weight=None, group=None):
+    """criterion(model(x), target) of train/main.py:196-202 with the last layer and the loss fused: the full-resolution
+    logits tensor is never materialised.  target: [N, H, W] int64."""
+    feats = encoder_forward(net.encoder, x, code=_compute_code(net, x))
+    y = feats
+    for layer in net.decoder.layers:
+        y = block_forward(layer, y)
+    oc = net.decoder.output_conv
+    return _HeadLossFn.apply(y, oc.weight, oc.bias, target, weight, group, oc)
 
 
 def erfnet_forward(net, x):

@@ -182,6 +182,27 @@ int erf_maxpool2x2_backward(const void* x, const void* dz, void* dx, int dtype, 
     return pool_bwd_launch(x, dz, dx, dtype, N, Hin, Win, Cin, ldz, zoff, accumulate, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------ output head fused with the loss
+size_t erf_output_conv_ce_workspace_bytes(int N, int Hin, int Win) {
+    if (N <= 0 || Hin <= 0 || Win <= 0) return 0;
+    return head_ce_workspace_bytes(N, Hin, Win);
+}
+
+int erf_output_conv_ce_fwd(const void* x, const void* packed, const float* bias, const long long* target, const float* weight,
+                           float* out3, void* workspace, int dtype, int N, int Hin, int Win, int nc, void* stream) {
+    if (!x || !packed || !bias || !target || !out3 || !workspace || !dtype_ok(dtype) || N <= 0 || Hin <= 0 || Win <= 0)
+        return ERF_EINVAL;
+    return head_ce_fwd_launch(x, packed, bias, target, weight, out3, (float*)workspace, dtype, N, Hin, Win, nc, (hipStream_t)stream);
+}
+
+int erf_output_conv_ce_bwd(const void* x, const void* packed, const float* bias, const long long* target, const float* weight,
+                           const float* coef, void* patches, int dtype, int N, int Hin, int Win, int nc, void* stream) {
+    if (!x || !packed || !bias || !target || !coef || !patches || !dtype_ok(dtype) || N <= 0 || Hin <= 0 || Win <= 0)
+        return ERF_EINVAL;
+    return head_ce_bwd_launch(x, packed, bias, target, weight, coef, patches, erf_output_conv_patch_channels(nc), dtype, N, Hin, Win,
+                              nc, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ loss
 size_t erf_ce_workspace_bytes(void) { return ce_workspace_bytes(); }
 

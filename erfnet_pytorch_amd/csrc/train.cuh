@@ -68,3 +68,11 @@ int pool_mean_bwd_launch(const void* x, const float* dfeat, void* dx, int dtype,
 int linear_fwd_launch(const float* f, const float* w, const float* b, float* y, int N, int C, int K, hipStream_t stream);
 int linear_bwd_launch(const float* f, const float* w, const float* dy, float* df, float* dw, float* db, int N, int C, int K,
                       hipStream_t stream);
+// (sum w*nll, sum w) partial pairs -> out3 = (num, den, num / den), fixed order
+int ce_partials_finalize_launch(const float* partials, long long groups, float* out3, hipStream_t stream);
+// Decoder.output_conv fused with the weighted cross entropy (head_loss.hip)
+size_t head_ce_workspace_bytes(int N, int Hin, int Win);
+int head_ce_fwd_launch(const void* x, const void* packed, const float* bias, const long long* target, const float* weight,
+                       float* out3, float* workspace, int dtype, int N, int Hin, int Win, int nc, hipStream_t stream);
+int head_ce_bwd_launch(const void* x, const void* packed, const float* bias, const long long* target, const float* weight,
+                       const float* coef, void* patches, int ld, int dtype, int N, int Hin, int Win, int nc, hipStream_t stream);

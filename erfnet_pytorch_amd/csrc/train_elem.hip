@@ -545,6 +545,12 @@ __global__ void ce_finalize_kernel(const float* __restrict__ partials, int group
     if (threadIdx.x == 0) { out[0] = (float)a; out[1] = (float)b; out[2] = (float)(a / b); }
 }
 
+int ce_partials_finalize_launch(const float* partials, long long groups, float* out3, hipStream_t stream) {
+    if (groups <= 0 || groups > 0x7FFFFFFFLL) return ERF_EINVAL;
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, (int)groups, out3);
+    return erf_check_launch();
+}
+
 size_t ce_workspace_bytes() { return (size_t)RED_MAX_GROUPS * 2 * sizeof(float); }
 
 int ce_fwd_launch(const void* z, int dtype, const long long* target, const float* weight, int N, int C, long long HW,

@@ -72,12 +72,15 @@ def _refresh_bank(bank, model, images):
 
 class Trainer:
     def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
-                 group=None, world_size=1, overlap=True, only_encode=False):
+                 group=None, world_size=1, overlap=True, only_encode=False, fused_head_loss=True):
         """`only_encode`: the first stage of the reference's recipe (train/main.py:495 `train(args, model, True)`,
         :203 `model(inputs, only_encode=enc)`): logits from Encoder.output_conv at 1/8 resolution against targets of
         that size; the decoder's parameters take no part and are left untouched."""
         self.model = model
         self.only_encode = only_encode
+        # Decoder.output_conv + loss in one pass each way (the logits stay in registers); step() then returns
+        # (loss, None).  Set False to get the logits back, e.g. for an IoU over the training batches.
+        self.fused_head_loss = fused_head_loss and not only_encode
         self.group, self.world = group, world_size
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_count = 0
@@ -157,14 +160,22 @@ class Trainer:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
         self.zero_grad()                                              # optimizer.zero_grad(), train/main.py:200
         self._refresh_packed(images)
-        outputs = self.model(images, only_encode=True) if self.only_encode else self.model(images)
-        _flush_batch_counters(self._counted)
-        loss = weighted_cross_entropy(outputs, targets, self.weight, self.group if self.world > 1 else None)
+        group = self.group if self.world > 1 else None
+        if self.fused_head_loss:
+            from . import ops
+            ops.require_gpu(images, "Trainer")
+            outputs = None
+            loss = ag.erfnet_forward_loss(self.model, images, targets, self.weight, group)
+            _flush_batch_counters(self._counted)
+        else:
+            outputs = self.model(images, only_encode=True) if self.only_encode else self.model(images)
+            _flush_batch_counters(self._counted)
+            loss = weighted_cross_entropy(outputs, targets, self.weight, group)
         loss.backward()
         ag.flush_bias_sums()
         self._reduce_gradients()
         self.optimizer_step()
-        return loss.detach(), outputs.detach()
+        return loss.detach(), None if outputs is None else outputs.detach()
 
     def _refresh_packed(self, images):
         self._bank = _refresh_bank(self._bank, self.model, images)

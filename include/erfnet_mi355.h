@@ -307,6 +307,19 @@ int erf_conv1d_factorized_bn(const void* x, void* z, const void* packed, const f
                              float* shift, void* workspace, void* stream);
 int erf_conv1d_dgrad_bias(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual, int dtype,
                           int N, int H, int W, int C, int axis, int dilation, float* dbias, void* workspace, void* stream);
+/* ---- Decoder.output_conv fused with the loss (training; train/erfnet.py:171,179 + train/main.py:121,202) ----------
+ * erf_output_conv_ce_fwd: out3 = (sum_p w[t_p] * nll_p, sum_p w[t_p], their ratio) of the logits
+ *   output_conv(x) + bias against target [N, 2Hin, 2Win] (int64), the logits living in registers only (packed:
+ *   erf_output_conv_pack; weight: [nc] or NULL; workspace: erf_output_conv_ce_workspace_bytes).
+ * erf_output_conv_ce_bwd: the same logits again, d logits = coef[0] * w[t] * (softmax - onehot) written as the patch
+ *   tensor [N, Hin, Win, erf_output_conv_patch_channels(nc)] that erf_output_conv_wgrad / erf_output_conv_dgrad take
+ *   (coef: one float in device memory = upstream gradient / global denominator). */
+size_t erf_output_conv_ce_workspace_bytes(int N, int Hin, int Win);
+int erf_output_conv_ce_fwd(const void* x, const void* packed, const float* bias, const long long* target, const float* weight,
+                           float* out3, void* workspace, int dtype, int N, int Hin, int Win, int nc, void* stream);
+int erf_output_conv_ce_bwd(const void* x, const void* packed, const float* bias, const long long* target, const float* weight,
+                           const float* coef, void* patches, int dtype, int N, int Hin, int Win, int nc, void* stream);
+
 /* erf_conv1d_dgrad_bias in two parts, so that the bias gradients of a whole backward pass are finished by one launch:
  * erf_conv1d_dgrad_bias_partial leaves the partial rows in `workspace` (erf_bn_workspace_bytes(C)) and returns their
  * number (> 0; negative: status); erf_channel_sum_finalize_many(table, count) takes `count` rows of

@@ -352,7 +352,7 @@ def test_trainer_step_matches_golden_and_autograd():
     loss_ref = CrossEntropyLoss2d(torch.tensor(O.CITYSCAPES_WEIGHTS)).to(DEV)(ref_model(x), t[:, 0])
     loss_ref.backward()
     model = build()
-    tr = Trainer(model, CITYSCAPES_WEIGHTS)
+    tr = Trainer(model, CITYSCAPES_WEIGHTS, fused_head_loss=False)      # same kernels as the module path: bitwise comparison below
     tr.lr = poly_lr(5e-4, 1, 150)
     assert abs(tr.lr - float(g["s0_lr"])) < 1e-12
     before = {k: p.detach().clone() for k, p in model.named_parameters()}
@@ -572,6 +572,41 @@ def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, exp
             continue
         err = rel_err(p.grad.cpu(), q.grad.cpu())
         assert err <= tol, (k, err)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 8e-2)])
+def test_fused_output_head_and_loss_equals_separate_kernels(dtype, tol):
+    """Trainer(fused_head_loss=True): Decoder.output_conv + weighted CE with the logits kept in registers gives the loss and
+    the gradients of the separate output_conv / CrossEntropyLoss2d / patch kernels (fp32: summation order only; bf16: the
+    rounding of d logits to bf16 happens at the same place, the rest is the backward pass's usual bf16 spread)."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    sd = O.synthetic_state(O.erfnet_template(20))
+    x = S.synthetic_images(2, 128, 256, seed=95).to(DEV)
+    t = S.synthetic_labels(2, 128, 256, 20, seed=95).to(DEV)
+
+    def run(fused):
+        m = E.ERFNet(20)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        m.compute_dtype = torch.bfloat16 if dtype == torch.bfloat16 else None
+        for mod in m.modules():
+            if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
+                mod.__dict__["_erf_forced_mask"] = torch.ones(2, mod.conv3x1_1.out_channels)
+        tr = Trainer(m, CITYSCAPES_WEIGHTS, fused_head_loss=fused)
+        loss, out = tr.step(x, t)
+        assert (out is None) == fused
+        return tr, loss.item()
+
+    tra, la = run(True)
+    trb, lb = run(False)
+    assert abs(la - lb) <= 2e-6 * abs(lb), (la, lb)
+    for k, (o, n) in tra.offsets.items():
+        if pre_bn_bias(k) or k.startswith("encoder.output_conv"):
+            continue
+        ga, gb = tra.gflat[o:o + n].cpu(), trb.gflat[o:o + n].cpu()
+        bar = 1e-5 if (dtype == torch.float32 and k.startswith("decoder.output_conv")) else tol
+        assert rel_err(ga, gb) <= bar, (k, rel_err(ga, gb))
 
 
 def test_caches_follow_raw_pointer_parameter_updates():
