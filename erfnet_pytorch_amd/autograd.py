@@ -130,8 +130,8 @@ def flush_bias_sums():
             call("erf_channel_sum_finalize_many", table.data_ptr(), len(rows), _stream())
     for dev, ents in wtodo:
         with torch.cuda.device(dev):
-            table = torch.cat([e[0] for e in ents]).to(torch.device("cuda", dev), non_blocking=False)
-            call("erf_wgrad_reduce_many", table.data_ptr(), len(ents), max(e[1] for e in ents), _stream())
+            table = torch.cat([e[0] for e in ents])
+            call("erf_wgrad_reduce_many", table.data_ptr(), len(ents), _stream())
 
 
 def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=None, defer=False):

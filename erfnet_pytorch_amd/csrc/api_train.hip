@@ -455,8 +455,8 @@ int erf_conv1d_wgrad_partial(const void* x, const void* dz, float* dw, int dtype
     return d->partial ? ERF_OK : ERF_ELAUNCH;           // the contraction must have reached (and deferred) its reduction
 }
 
-int erf_wgrad_reduce_many(const void* table_dev, int count, int max_total, void* stream) {
-    return wgrad_reduce_many_launch(table_dev, count, max_total, (hipStream_t)stream);
+int erf_wgrad_reduce_many(const void* table, int count, void* stream) {
+    return wgrad_reduce_many_launch(table, count, (hipStream_t)stream);
 }
 
 int erf_downsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, int N, int Hin, int Win, int Cin, int Cout,

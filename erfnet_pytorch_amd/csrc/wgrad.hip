@@ -205,11 +205,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// The same reduction for a table of descriptors (device memory): blockIdx.y = entry, blockIdx.x = block of 32 elements.
-__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const WgradReduceDesc* __restrict__ table) {
+// The same reduction for a table of descriptors that travels as the kernel's argument (no upload, nothing for a captured
+// graph to read from host memory later): blockIdx.y = entry, blockIdx.x = block of 32 elements.
+#define ERF_WGRAD_REDUCE_CHUNK 26                                    /* 26 * 152 B stays below the 4 KB of kernel arguments */
+struct WgradReduceTable { WgradReduceDesc d[ERF_WGRAD_REDUCE_CHUNK]; };
+static_assert(sizeof(WgradReduceTable) <= 4096, "descriptor table must fit the kernel-argument segment");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const WgradReduceTable table) {
     constexpr int E = 32, S = 8;
     __shared__ double sh[S][E];
-    const WgradReduceDesc& d = table[blockIdx.y];
+    const WgradReduceDesc& d = table.d[blockIdx.y];
     const PackParams& m = d.m;
     const int total = m.cout_virtual * m.ntaps * d.cin;
     if ((int)blockIdx.x * E >= total) return;
@@ -248,11 +253,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const WgradReduc
     }
 }
 
-int wgrad_reduce_many_launch(const void* table_dev, int count, int max_total, hipStream_t stream) {
-    if (!table_dev || count <= 0 || max_total <= 0) return ERF_EINVAL;
-    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((max_total + 31) / 32, count), dim3(256), 0, stream,
-                       (const WgradReduceDesc*)table_dev);
-    return erf_check_launch();
+int wgrad_reduce_many_launch(const void* table_host, int count, hipStream_t stream) {
+    if (!table_host || count <= 0) return ERF_EINVAL;
+    const WgradReduceDesc* src = (const WgradReduceDesc*)table_host;
+    for (int base = 0; base < count; base += ERF_WGRAD_REDUCE_CHUNK) {
+        const int n = count - base < ERF_WGRAD_REDUCE_CHUNK ? count - base : ERF_WGRAD_REDUCE_CHUNK;
+        WgradReduceTable t;
+        int max_total = 0;
+        for (int i = 0; i < n; ++i) {
+            t.d[i] = src[base + i];
+            if (!t.d[i].partial || !t.d[i].dw) return ERF_EINVAL;
+            const int total = t.d[i].m.cout_virtual * t.d[i].m.ntaps * t.d[i].cin;
+            max_total = total > max_total ? total : max_total;
+        }
+        for (int i = n; i < ERF_WGRAD_REDUCE_CHUNK; ++i) t.d[i] = t.d[0];
+        if (max_total <= 0) return ERF_EINVAL;
+        hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((max_total + 31) / 32, n), dim3(256), 0, stream, t);
+        const int rc = erf_check_launch();
+        if (rc) return rc;
+    }
+    return ERF_OK;
 }
 
 // While a descriptor slot is set for the calling thread, the next reduction is not launched: its arguments are written

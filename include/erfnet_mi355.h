@@ -271,12 +271,13 @@ int erf_downsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, i
                           void* workspace, size_t workspace_bytes, void* stream);
 /* erf_conv1d_wgrad in two parts, so that all weight-gradient reductions of a backward pass run as one launch:
  * erf_conv1d_wgrad_partial leaves the partial tiles in `workspace` and the pending reduction's arguments in `desc`
- * (host memory, erf_wgrad_reduce_desc_bytes()); the caller gathers the descriptors into a device table and
- * erf_wgrad_reduce_many(table, count, max_total = largest 3*C*C) writes every dW. */
+ * (host memory, erf_wgrad_reduce_desc_bytes()); the caller gathers the descriptors into one host table and
+ * erf_wgrad_reduce_many(table, count) writes every dW (the table travels as kernel arguments: nothing is uploaded, the
+ * host memory is free again when the call returns). */
 size_t erf_wgrad_reduce_desc_bytes(void);
 int erf_conv1d_wgrad_partial(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis,
                              int dilation, void* workspace, size_t workspace_bytes, void* desc, void* stream);
-int erf_wgrad_reduce_many(const void* table_dev, int count, int max_total, void* stream);
+int erf_wgrad_reduce_many(const void* table, int count, void* stream);
 int erf_image_to_nhwc_padded(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, void* stream);
 int erf_stem_wgrad(const void* x_pad, const void* dz, float* dw, int dtype, int N, int Hin, int Win, void* workspace,
                    size_t workspace_bytes, void* stream);
