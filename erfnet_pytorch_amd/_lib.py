@@ -153,3 +153,16 @@ def call(name: str, *args):
 def query(name: str, *args):
     """Invoke a size/version query."""
     return _fn[name](*args)
+
+
+_SIZES = {}
+
+
+def size_query(name: str, *args):
+    """query() for the pure size functions (workspace / packed-buffer bytes, padded channel counts): the answer depends on
+    the arguments only, so it is remembered -- a training step asks several hundred of them."""
+    key = (name,) + args
+    v = _SIZES.get(key)
+    if v is None:
+        v = _SIZES[key] = _fn[name](*args)
+    return v

@@ -15,13 +15,13 @@ import threading
 import torch
 
 from . import ops
-from ._lib import AXIS_H, AXIS_W, BF16, F32, call, query
+from ._lib import AXIS_H, AXIS_W, BF16, F32, call, query, size_query
 
 _mask_counter = [0]
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _p(t):
@@ -66,7 +66,7 @@ def bn_forward_stats(z, bn, training):
         invstd = torch.empty(c, device=dev)
         scale = torch.empty(c, device=dev)
         shift = torch.empty(c, device=dev)
-        ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+        ws = _ws(size_query("erf_bn_workspace_bytes", c), dev)
         track = bn.track_running_stats and bn.running_mean is not None
         momentum = 0.1 if bn.momentum is None else bn.momentum
         call("erf_bn_stats_finalize", z.data_ptr(), ops.dt(z), z.numel() // c, c, gamma.data_ptr(), beta.data_ptr(),
@@ -90,7 +90,7 @@ def conv1d_bn_stats(x, packed, bias, axis, dilation, bn, training):
         gamma, beta = _f32(bn.weight), _f32(bn.bias)
         mean, invstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
         scale, shift = torch.empty(c, device=dev), torch.empty(c, device=dev)
-        ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+        ws = _ws(size_query("erf_bn_workspace_bytes", c), dev)
         track = bn.track_running_stats and bn.running_mean is not None
         momentum = 0.1 if bn.momentum is None else bn.momentum
         rc = query("erf_conv1d_factorized_bn", x.data_ptr(), z.data_ptr(), packed.data_ptr(), bias.data_ptr(), ops.dt(x), n, h, w, c,
@@ -140,7 +140,7 @@ def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=No
     n, h, w, c = dy.shape
     dx = torch.empty_like(dy)
     db = torch.empty(c, device=dy.device) if dbias_out is None else dbias_out
-    ws = _ws(query("erf_bn_workspace_bytes", c), dy.device)
+    ws = _ws(size_query("erf_bn_workspace_bytes", c), dy.device)
     if defer:
         rc = query("erf_conv1d_dgrad_bias_partial", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), _p(gate), _p(residual),
                    ops.dt(dy), n, h, w, c, axis, dilation, ws.data_ptr(), _stream())
@@ -213,7 +213,7 @@ def conv1d_dgrad_bn_backward(dy, packed_t, gate, residual, axis, dilation, z, me
     dx, dz = torch.empty_like(dy), torch.empty_like(z)
     dgamma = torch.empty(c, device=dev) if dgamma is None else dgamma
     dbeta = torch.empty(c, device=dev) if dbeta is None else dbeta
-    ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+    ws = _ws(size_query("erf_bn_workspace_bytes", c), dev)
     rc = query("erf_conv1d_dgrad_bn_backward", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), gate.data_ptr(), _p(residual),
                ops.dt(dy), n, h, w, c, axis, dilation, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                _p(mask), int(batch_stats), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream())
@@ -241,7 +241,7 @@ def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=F
     g_out = torch.empty_like(z) if want_g_out else None
     dgamma = torch.empty(c, device=dev) if dgamma is None else dgamma
     dbeta = torch.empty(c, device=dev) if dbeta is None else dbeta
-    ws = _ws(query("erf_bn_workspace_bytes", c), dev)
+    ws = _ws(size_query("erf_bn_workspace_bytes", c), dev)
     call("erf_bn_backward", g.data_ptr(), _p(gate), _p(mask), z.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
          gamma.data_ptr(), int(batch_stats), dz.data_ptr(), _p(g_out), dgamma.data_ptr(), dbeta.data_ptr(), ops.dt(z), n,
          h * w, c, ws.data_ptr(), _stream())
@@ -251,7 +251,7 @@ def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=F
 def channel_sum(z, out=None):
     c = z.shape[-1]
     out = torch.empty(c, device=z.device) if out is None else out
-    ws = _ws(query("erf_bn_workspace_bytes", c), z.device)
+    ws = _ws(size_query("erf_bn_workspace_bytes", c), z.device)
     call("erf_channel_sum", z.data_ptr(), ops.dt(z), z.numel() // c, c, out.data_ptr(), ws.data_ptr(), _stream())
     return out
 
@@ -282,16 +282,16 @@ def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None, defer=False):
     n, h, w, c = x.shape
     if defer:
         dw = torch.empty(wshape, device=x.device) if out is None else out
-        nb = query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
+        nb = size_query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
         ws = _ws(nb, x.device)
-        desc = torch.zeros(query("erf_wgrad_reduce_desc_bytes"), dtype=torch.uint8)
+        desc = torch.zeros(size_query("erf_wgrad_reduce_desc_bytes"), dtype=torch.uint8)
         call("erf_conv1d_wgrad_partial", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ops.dt(x), n, h, w, c, axis, dilation,
              ws.data_ptr(), nb, desc.data_ptr(), _stream())
         with _PENDING_LOCK:
             _PENDING_WGRAD.setdefault(x.device.index, []).append((desc, 3 * c * c, ws, dw))
         return dw
     dw = torch.empty(wshape, device=x.device) if out is None else out
-    nb = query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
+    nb = size_query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
     ws = _ws(nb, x.device)
     call("erf_conv1d_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ops.dt(x), n, h, w, c, axis, dilation,
          ws.data_ptr(), nb, _stream())
@@ -463,12 +463,12 @@ class _DownFn(torch.autograd.Function):
             cpad = 8 if code == BF16 else 4
             xpad = torch.empty((n, 2 * ho, 2 * wo, cpad), dtype=z.dtype, device=dev)
             call("erf_image_to_nhwc_padded", xh.data_ptr(), ops.dt(xh), xpad.data_ptr(), code, n, 2 * ho, 2 * wo, _stream())
-            nb = query("erf_wgrad_workspace_bytes", 13, cpad, 9, n * ho * wo)
+            nb = size_query("erf_wgrad_workspace_bytes", 13, cpad, 9, n * ho * wo)
             ws = _ws(nb, dev)
             call("erf_stem_wgrad", xpad.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, ws.data_ptr(), nb,
                  _stream())
             return (None, None) + sk.ret(dw, db, dgamma, dbeta)
-        nb = query("erf_wgrad_workspace_bytes", cc, cin, 9, n * ho * wo)
+        nb = size_query("erf_wgrad_workspace_bytes", cc, cin, 9, n * ho * wo)
         ws = _ws(nb, dev)
         call("erf_downsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
              ws.data_ptr(), nb, _stream())
@@ -515,7 +515,7 @@ class _UpFn(torch.autograd.Function):
                                                dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
         db = pre_bn_bias_grad(dz, ctx.training, sk.out("conv.bias", (cout,), dev), sk.zeroed)
         dw = sk.out("conv.weight", w.shape, dev)
-        nb = query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)
+        nb = size_query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)
         ws = _ws(nb, dev)
         call("erf_upsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, cout, ws.data_ptr(), nb,
              _stream())
@@ -545,7 +545,7 @@ class _OutConvFn(torch.autograd.Function):
         n, h, wd, _ = xh.shape
         nc = w.shape[1]
         glogits = glogits.contiguous()
-        ld = query("erf_output_conv_patch_channels", nc)
+        ld = size_query("erf_output_conv_patch_channels", nc)
         patches = torch.empty((n, h, wd, ld), dtype=xh.dtype, device=dev)
         call("erf_output_conv_patches", glogits.data_ptr(), ops.dt(glogits), patches.data_ptr(), code, n, h, wd, nc, _stream())
         return _outconv_backward(ctx.mod, xh, w, patches) + (None, None)
@@ -560,7 +560,7 @@ def _outconv_backward(mod, xh, w, patches):
     db = sk.out("bias", (nc,), dev)
     db.copy_(channel_sum(patches)[: 4 * nc].reshape(nc, 4).sum(1))
     dw = sk.out("weight", w.shape, dev)
-    nb = query("erf_wgrad_workspace_bytes", 4 * nc, 16, 1, n * h * wd)
+    nb = size_query("erf_wgrad_workspace_bytes", 4 * nc, 16, 1, n * h * wd)
     ws = _ws(nb, dev)
     call("erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc, ws.data_ptr(), nb,
          _stream())
@@ -589,7 +589,7 @@ class _HeadLossFn(torch.autograd.Function):
         packed = ops.packed_generic(mod, "fwd", w, code, lambda: ops.pack_output_conv(w, code))
         bias = _f32(b)
         out3 = torch.empty(3, device=dev)
-        ws = _ws(query("erf_output_conv_ce_workspace_bytes", n, h, wd), dev)
+        ws = _ws(size_query("erf_output_conv_ce_workspace_bytes", n, h, wd), dev)
         call("erf_output_conv_ce_fwd", xh.data_ptr(), packed.data_ptr(), bias.data_ptr(), target.data_ptr(), _p(wt), out3.data_ptr(),
              ws.data_ptr(), code, n, h, wd, nc, _stream())
         num, den = global_weighted_mean(out3[0], out3[1], group)
@@ -604,7 +604,7 @@ class _HeadLossFn(torch.autograd.Function):
         n, h, wd, _ = xh.shape
         nc = w.shape[1]
         coef = (gout.reshape(1).float() / den).contiguous()
-        patches = torch.empty((n, h, wd, query("erf_output_conv_patch_channels", nc)), dtype=xh.dtype, device=dev)
+        patches = torch.empty((n, h, wd, size_query("erf_output_conv_patch_channels", nc)), dtype=xh.dtype, device=dev)
         call("erf_output_conv_ce_bwd", xh.data_ptr(), packed.data_ptr(), bias.data_ptr(), target.data_ptr(), _p(ctx.weight),
              coef.data_ptr(), patches.data_ptr(), code, n, h, wd, nc, _stream())
         return _outconv_backward(ctx.mod, xh, w, patches) + (None, None, None, None)
@@ -632,14 +632,14 @@ class _PointwiseFn(torch.autograd.Function):
         n, h, wd, cin = xh.shape
         nc = w.shape[0]
         glogits = glogits.contiguous()
-        ld = query("erf_pointwise_grad_channels", nc)
+        ld = size_query("erf_pointwise_grad_channels", nc)
         g = torch.empty((n, h, wd, ld), dtype=xh.dtype, device=dev)
         call("erf_pointwise_grad_nhwc", glogits.data_ptr(), ops.dt(glogits), g.data_ptr(), code, n, h, wd, nc, _stream())
         sk = _Sink(ctx.mod)
         db = sk.out("bias", (nc,), dev)
         db.copy_(channel_sum(g)[:nc])
         dw = sk.out("weight", w.shape, dev)
-        nb = query("erf_wgrad_workspace_bytes", nc, cin, 1, n * h * wd)
+        nb = size_query("erf_wgrad_workspace_bytes", nc, cin, 1, n * h * wd)
         ws = _ws(nb, dev)
         call("erf_pointwise_wgrad", xh.data_ptr(), g.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, nc, ws.data_ptr(), nb,
              _stream())

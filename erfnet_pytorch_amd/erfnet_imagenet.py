@@ -46,7 +46,7 @@ class non_bottleneck_1d(E.non_bottleneck_1d):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 class _PoolMeanFn(torch.autograd.Function):

@@ -21,7 +21,7 @@ from .dp import global_weighted_mean
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 class _WeightedCE(torch.autograd.Function):

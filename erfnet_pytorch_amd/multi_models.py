@@ -22,7 +22,7 @@ __all__ = ["DownsamplerBlock_simplified", "non_bottleneck_1d", "Encoder", "Upsam
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _inference_only(mod, x):

@@ -232,7 +232,7 @@ class Trainer:
         from . import ops
         ops.bump_param_epoch()                          # parameters change below through raw pointers
         self.step_count += 1
-        st = torch.cuda.current_stream().cuda_stream
+        st = ops._stream()
         for lo, hi in self.active:
             call("erf_adam_fused_arena", self.flat[lo:hi].data_ptr(), self.gflat[lo:hi].data_ptr(),
                  self.exp_avg[lo:hi].data_ptr(), self.exp_avg_sq[lo:hi].data_ptr(), hi - lo, float(self.lr),
@@ -298,7 +298,7 @@ class ArenaSGD:
         ops.bump_param_epoch()
         call("erf_sgd_fused_arena", self.flat.data_ptr(), self.gflat.data_ptr(), self.buf.data_ptr(), self.flat.numel(),
              float(self.lr), float(self.momentum), float(self.wd), int(self.step_count == 0), 1.0,
-             torch.cuda.current_stream().cuda_stream)
+             ops._stream())
         self.step_count += 1
         return loss.detach(), outputs.detach()
 
