@@ -136,3 +136,36 @@ def test_multi_models_state_dict_matches_reference_layout():
     import torch
     with pytest.raises(RuntimeError):                  # no CPU path: fails loudly
         m.eval()(torch.zeros(1, 3, 64, 128))
+
+
+def test_tolerant_loader_and_checkpoint_dict_follow_the_reference_conventions(tmp_path):
+    """eval/eval_iou.py:54-65 (`module.` prefix accepted, unknown names reported and skipped, partial dictionaries fine) and
+    train/main.py:320-326 (checkpoint dictionary with DataParallel-style names, readable by a loader that executes nothing)."""
+    import torch
+    from erfnet_pytorch_amd import erfnet as E, checkpoint as C, synthetic as S
+    src = E.ERFNet(20)
+    S.load_synthetic(src, salt=3)
+    sd = {"module." + k: v.clone() for k, v in src.state_dict().items()}
+    sd["module.not.there"] = torch.zeros(1)
+    del sd["module.decoder.output_conv.bias"]
+    dst = E.ERFNet(20)
+    before = dst.decoder.output_conv.bias.detach().clone()
+    seen = []
+    C.load_my_state_dict(dst, sd, report=lambda *a: seen.append(a[0]))
+    assert seen == ["module.not.there"]
+    for k, v in src.state_dict().items():
+        if k == "decoder.output_conv.bias":
+            assert torch.equal(dst.state_dict()[k], before)
+        else:
+            assert torch.equal(dst.state_dict()[k], v), k
+
+    ck = C.checkpoint_dict(src, None, epoch=7, best_acc=0.5)
+    assert set(ck) == {"epoch", "arch", "state_dict", "best_acc"} and all(k.startswith("module.") for k in ck["state_dict"])
+    path, best = tmp_path / "checkpoint.pth.tar", tmp_path / "model_best.pth.tar"
+    C.save_checkpoint(ck, True, str(path), str(best))
+    other = E.ERFNet(20)
+    epoch, acc = C.resume(str(best), other)
+    assert (epoch, acc) == (7, 0.5)
+    for k, v in src.state_dict().items():
+        assert torch.equal(other.state_dict()[k], v), k
+    torch.nn.DataParallel(E.ERFNet(20)).load_state_dict(ck["state_dict"])      # what the reference's resume does with it

@@ -637,3 +637,45 @@ def test_caches_follow_raw_pointer_parameter_updates():
         y2 = fresh(x)
     assert rel_err(y1.cpu(), y0.cpu()) > 1e-3      # the parameters did move
     assert torch.equal(y1, y2)
+
+
+def test_checkpoint_file_round_trip_through_reference_format(tmp_path):
+    """checkpoint.save_checkpoint / resume (train/main.py:143-153, :320-326): a file with DataParallel-style names and the
+    optimiser state, written after step 1, read back (weights_only) into a fresh model + Trainer, continues bit-identically."""
+    from erfnet_pytorch_amd import erfnet as E, checkpoint as C
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    sd0 = O.synthetic_state(O.erfnet_template(20))
+    x = S.synthetic_images(2, 64, 128, seed=93).to(DEV)
+    t = S.synthetic_labels(2, 64, 128, 20, seed=93).to(DEV)
+
+    def build(state):
+        m = E.ERFNet(20)
+        if state is not None:
+            m.load_state_dict(state)
+        m = m.to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
+                mod.__dict__["_erf_forced_mask"] = torch.ones(2, mod.conv3x1_1.out_channels)
+        return m
+
+    a = build(sd0)
+    tra = Trainer(a, CITYSCAPES_WEIGHTS)
+    tra.set_epoch(3, 150)
+    tra.step(x, t)
+    path = tmp_path / "checkpoint.pth.tar"
+    C.save_checkpoint(C.checkpoint_dict(a, tra, epoch=4, best_acc=0.25), False, str(path), str(tmp_path / "best.pth.tar"))
+    b = build(None)
+    trb = Trainer(b, CITYSCAPES_WEIGHTS)
+    epoch, best = C.resume(str(path), b, trb, map_location=DEV)
+    assert (epoch, best) == (4, 0.25) and trb.step_count == 1 and trb.lr == tra.lr
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k]), k
+    la, _ = tra.step(x, t)
+    lb, _ = trb.step(x, t)
+    assert la.item() == lb.item()
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), k
+    # eval after resume uses the loaded weights (packed-weight caches follow the in-place load)
+    a.eval(); b.eval()
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x))
