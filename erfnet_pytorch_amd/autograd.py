@@ -298,6 +298,32 @@ def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None, defer=False):
     return dw
 
 
+def conv1d_wgrad_block(jobs):
+    """dW of several factorized convolutions on tensors of one shape -- jobs: (x, dz, dw_out, axis, dilation) -- by one
+    contraction launch where the library takes the shape (bf16, C in {16, 64, 128}), else layer by layer.  Complete after
+    flush_bias_sums()."""
+    x0 = jobs[0][0]
+    n, h, w, c = x0.shape
+    dev = x0.device
+    nb = size_query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
+    dsz = size_query("erf_wgrad_reduce_desc_bytes")
+    wss = [_ws(nb, dev) for _ in jobs]
+    table = torch.tensor([[x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), axis | (dil << 32)]
+                          for (x, dz, dw, axis, dil), ws in zip(jobs, wss)], dtype=torch.int64)
+    descs = torch.zeros(len(jobs) * dsz, dtype=torch.uint8)
+    rc = query("erf_conv1d_wgrad_partial_many", table.data_ptr(), len(jobs), ops.dt(x0), n, h, w, c, nb, descs.data_ptr(), _stream())
+    if rc == 0:
+        with _PENDING_LOCK:
+            pend = _PENDING_WGRAD.setdefault(dev.index, [])
+            for i, ((x, dz, dw, _, _), ws) in enumerate(zip(jobs, wss)):
+                pend.append((descs[i * dsz:(i + 1) * dsz], 3 * c * c, ws, dw))
+        return
+    if rc != -2:
+        raise RuntimeError(f"erf_conv1d_wgrad_partial_many failed with status {rc}")
+    for x, dz, dw, axis, dil in jobs:
+        conv1d_wgrad(x, dz, tuple(dw.shape), axis, dil, dw, defer=True)
+
+
 def dropout_mask(n, c, p, dev, forced=None):
     if forced is not None:
         return forced.to(dev, torch.float32).reshape(n, c).contiguous()
@@ -381,10 +407,10 @@ class _NB1dFn(torch.autograd.Function):
             dz4, g_res, dg2, dbe2 = bn_backward(g, out, ctx.mask, z4, mean2, invstd2, _f32(g2), ctx.training, want_g_out=True,
                                                 dgamma=o("bn2.weight", (c,)), dbeta=o("bn2.bias", (c,)))
         db4 = pre_bn_bias_grad(dz4, ctx.training, o("conv1x3_2.bias", (c,)), sk.zeroed)
-        dw4 = conv1d_wgrad(a3, dz4, w4.shape, AXIS_W, d, o("conv1x3_2.weight", w4.shape), defer=True)
+        dw4, dw3 = o("conv1x3_2.weight", w4.shape), o("conv3x1_2.weight", w3.shape)
+        dw2, dw1 = o("conv1x3_1.weight", w2.shape), o("conv3x1_1.weight", w1.shape)
         dz3, db3 = conv1d_dgrad_bias(dz4, ops.packed_conv1d(ctx.mod, "conv1x3_2", w4, code, 1), a3, None, AXIS_W, d,
                                      o("conv3x1_2.bias", (c,)), defer=True)
-        dw3 = conv1d_wgrad(a2, dz3, w3.shape, AXIS_H, d, o("conv3x1_2.weight", w3.shape), defer=True)
         fused = conv1d_dgrad_bn_backward(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), a2, None, AXIS_H, d, z2,
                                          mean1, invstd1, _f32(g1), None, ctx.training, o("bn1.weight", (c,)),
                                          o("bn1.bias", (c,))) if FUSE_BN_BACKWARD else None
@@ -395,10 +421,8 @@ class _NB1dFn(torch.autograd.Function):
             dz2, _, dg1, dbe1 = bn_backward(da2, a2, None, z2, mean1, invstd1, _f32(g1), ctx.training,
                                             dgamma=o("bn1.weight", (c,)), dbeta=o("bn1.bias", (c,)))
         db2 = pre_bn_bias_grad(dz2, ctx.training, o("conv1x3_1.bias", (c,)), sk.zeroed)
-        dw2 = conv1d_wgrad(a1, dz2, w2.shape, AXIS_W, 1, o("conv1x3_1.weight", w2.shape), defer=True)
         dz1, db1 = conv1d_dgrad_bias(dz2, ops.packed_conv1d(ctx.mod, "conv1x3_1", w2, code, 1), a1, None, AXIS_W, 1,
                                      o("conv3x1_1.bias", (c,)), defer=True)
-        dw1 = conv1d_wgrad(xh, dz1, w1.shape, AXIS_H, 1, o("conv3x1_1.weight", w1.shape), defer=True)
         t, fused = ctx.tail, None
         if t is not None:                     # this block's input is the ReLU output of a BatchNorm: run that layer's backward here
             psk = _Sink(t.mod)
@@ -410,6 +434,8 @@ class _NB1dFn(torch.autograd.Function):
             _HANDOFF.slot = (dx.data_ptr(), tuple(dx.shape), fused[1:])
         else:
             dx = conv1d_dgrad(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), None, g_res, AXIS_H, 1)
+        # the block's four weight gradients are leaves: one launch for all of them, behind the data path
+        conv1d_wgrad_block([(a3, dz4, dw4, AXIS_W, d), (a2, dz3, dw3, AXIS_H, d), (a1, dz2, dw2, AXIS_W, 1), (xh, dz1, dw1, AXIS_H, 1)])
         return (ops.to_nchw_view(dx), None) + sk.ret(dw1, db1, dw2, db2, dg1, dbe1, dw3, db3, dw4, db4, dg2, dbe2)
 
 

@@ -455,6 +455,32 @@ int erf_conv1d_wgrad_partial(const void* x, const void* dz, float* dw, int dtype
     return d->partial ? ERF_OK : ERF_ELAUNCH;           // the contraction must have reached (and deferred) its reduction
 }
 
+// The weight gradients of up to 4 factorized convolutions on tensors of one shape (the four of a non_bottleneck_1d block)
+// as ONE contraction launch; like erf_conv1d_wgrad_partial the reductions are left pending in descs[count].
+int erf_conv1d_wgrad_partial_many(const erf_wgrad_job* jobs, int count, int dtype, int N, int H, int W, int C,
+                                  size_t workspace_bytes, void* descs, void* stream) {
+    static_assert(sizeof(erf_wgrad_job) == sizeof(W1dJob), "erf_wgrad_job is W1dJob");
+    if (!jobs || !descs || count < 1 || count > 4 || !dtype_ok(dtype) || N <= 0) return ERF_EINVAL;
+    PackParams maps[4];
+    W1dJob w[4];
+    for (int i = 0; i < count; ++i) {
+        if (!jobs[i].x || !jobs[i].dz || !jobs[i].dw || !jobs[i].workspace || jobs[i].dilation < 1 ||
+            (jobs[i].axis != ERF_AXIS_H && jobs[i].axis != ERF_AXIS_W))
+            return ERF_EINVAL;
+        PackParams m{};
+        m.cin = C; m.cout_virtual = C; m.ncp = NO_PHASES; m.nc_valid = C; m.s_co = 3LL * C; m.s_ci = 3; m.ntaps = 3;
+        m.toff[0] = 0; m.toff[1] = 1; m.toff[2] = 2;
+        maps[i] = m;
+        w[i] = W1dJob{jobs[i].x, jobs[i].dz, jobs[i].dw, (float*)jobs[i].workspace, jobs[i].axis, jobs[i].dilation};
+        ((WgradReduceDesc*)descs)[i].partial = nullptr;
+    }
+    const int rc = wgrad1d_many_launch(w, count, dtype, N, H, W, C, maps, workspace_bytes, (WgradReduceDesc*)descs, (hipStream_t)stream);
+    if (rc) return rc;
+    for (int i = 0; i < count; ++i)
+        if (!((WgradReduceDesc*)descs)[i].partial) return ERF_ELAUNCH;
+    return ERF_OK;
+}
+
 int erf_wgrad_reduce_many(const void* table, int count, void* stream) {
     return wgrad_reduce_many_launch(table, count, (hipStream_t)stream);
 }

@@ -60,6 +60,11 @@ int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_p
 // Factorized-convolution weight gradient on lattice tiles (bf16).  ERF_EUNSUPPORTED: use wgrad_launch.
 int wgrad1d_launch(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis, int dilation,
                    const PackParams& map, float* workspace, size_t workspace_bytes, hipStream_t stream);
+// Up to 4 layers of one shape [N, H, W, C] in one launch (each with its own operands, axis, dilation and workspace of
+// workspace_bytes); descs != nullptr: the per-layer reductions are not launched, their arguments are written there.
+struct W1dJob { const void* x; const void* dz; float* dw; float* workspace; int axis, dilation; };
+int wgrad1d_many_launch(const W1dJob* jobs, int count, int dtype, int N, int H, int W, int C, const PackParams* maps,
+                        size_t workspace_bytes, WgradReduceDesc* descs, hipStream_t stream);
 
 // ---- classifier head of the ImageNet variant (head.hip)
 int spatial_mean_launch(const void* x, int dtype, float* feat, int N, long long HW, int C, hipStream_t stream);

@@ -14,6 +14,9 @@
 //  * accumulators stay in registers over ALL tiles of the (persistent) workgroup; there is no
 //    per-tile epilogue.  Each workgroup writes one fp32 partial tile at the end and
 //    wgrad_reduce_kernel sums the partials in a fixed order (bit-reproducible, no atomics).
+//  * one launch takes up to ERF_W1D_MAX layers of the same shape (blockIdx.y = layer): the four convolutions of a
+//    non_bottleneck_1d block share the chip, each with a quarter of the workgroups and four times the pixels per
+//    workgroup -- a quarter of the partial tiles to write and to sum afterwards.
 // Wave layout: column groups (3*C/16 column tiles split over waves) x KW waves along the pixel axis.
 #include "common.cuh"
 #include "train.cuh"
@@ -33,6 +36,9 @@ struct W1dParams {
     FastDiv fCB, fCA, fD;
     uint32_t bytes, pad;
 };
+
+#define ERF_W1D_MAX 4
+struct W1dTable { W1dParams p[ERF_W1D_MAX]; };
 
 struct W1dGeo {
     uint32_t soff;
@@ -74,8 +80,9 @@ __device__ __forceinline__ void tie_reg2(i32x2& v) { asm volatile("" : "+v"(v));
 
 template <int C, int CG, int KW, int CPW, int M, int KIX, int KIZ, int OCC>
 __global__ __launch_bounds__(CG * KW * 64, OCC)
-void wgrad1d_kernel(const W1dParams p) {
+void wgrad1d_kernel(const W1dTable tab) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const W1dParams& p = tab.p[blockIdx.y];
     constexpr int CH = C / 8;
     constexpr int PIXB = C * 2;
     constexpr int NW = CG * KW;
@@ -250,13 +257,10 @@ void wgrad1d_kernel(const W1dParams p) {
 
 static inline int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// Geometry of one layer (everything but the output pointer and the grid).
 template <int C, int CG, int KW, int CPW, int M, int KIX, int KIZ>
-static int launch_w1d(W1dParams p, int N, int H, int W, int axis, const PackParams& map, float* dw, float* workspace,
-                      size_t workspace_bytes, hipStream_t stream) {
+static int prep_w1d(W1dParams& p, int N, int H, int W, int axis) {
     constexpr int CH = C / 8, PIXB = C * 2, NW = CG * KW;
-    constexpr size_t lds = 2 * (size_t)(KIX + KIZ) * NW * 1024;
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    constexpr int OCC = (2 * lds <= 160 * 1024 && NW <= 4) ? 2 : 1;
     const int d = p.d;
     if (axis == 0) {
         p.A = H; p.Bn = W; p.nimg = N; p.img_stride = (long long)H * W; p.stride_u = d * W; p.stride_v = 1;
@@ -279,31 +283,66 @@ static int launch_w1d(W1dParams p, int N, int H, int W, int axis, const PackPara
     const long long bytes = (long long)N * H * W * PIXB, pad = (long long)p.stride_u * PIXB;
     if (bytes + (long long)(Tm + 3) * pad >= 0x7FFFFFFFLL) return ERF_EUNSUPPORTED;
     p.bytes = (uint32_t)bytes; p.pad = (uint32_t)pad;
+    return ERF_OK;
+}
+
+// `count` layers of one shape in one launch; layer i reduces into dw[i] (through wgrad_reduce_launch, which a caller may
+// have put off with wgrad_reduce_defer -- then only for count == 1).  descs != nullptr: the reductions' arguments go there.
+template <int C, int CG, int KW, int CPW, int M, int KIX, int KIZ>
+static int launch_w1d(const W1dJob* jobs, int count, int N, int H, int W, const PackParams* maps, size_t workspace_bytes,
+                      WgradReduceDesc* descs, hipStream_t stream) {
+    constexpr int NW = CG * KW;
+    constexpr size_t lds = 2 * (size_t)(KIX + KIZ) * NW * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    constexpr int OCC = (2 * lds <= 160 * 1024 && NW <= 4) ? 2 : 1;
+    if (count < 1 || count > ERF_W1D_MAX) return ERF_EINVAL;
+    W1dTable tab{};
+    int ntiles_min = 0x7FFFFFFF;
+    for (int i = 0; i < count; ++i) {
+        W1dParams& p = tab.p[i];
+        p.x = jobs[i].x; p.dz = jobs[i].dz; p.d = jobs[i].dilation;
+        const int rc = prep_w1d<C, CG, KW, CPW, M, KIX, KIZ>(p, N, H, W, jobs[i].axis);
+        if (rc) return rc;
+        p.partial = jobs[i].workspace;
+        ntiles_min = p.ntiles < ntiles_min ? p.ntiles : ntiles_min;
+    }
+    for (int i = count; i < ERF_W1D_MAX; ++i) tab.p[i] = tab.p[0];
+    // one layer alone: 128 workgroups per unit of occupancy (more only adds partial tiles); several layers share twice that
     static const int want = getenv("ERF_WGRAD1D_WGS") ? atoi(getenv("ERF_WGRAD1D_WGS")) : 128;
+    static const int want_many = getenv("ERF_WGRAD1D_WGS_MANY") ? atoi(getenv("ERF_WGRAD1D_WGS_MANY")) : 256;
     const size_t tile_bytes = (size_t)C * 3 * C * sizeof(float);
-    long long grid = want * OCC;
-    if (grid > p.ntiles) grid = p.ntiles;
+    long long grid = count == 1 ? (long long)want * OCC : (long long)want_many * OCC / count;
+    if (grid > ntiles_min) grid = ntiles_min;
     if ((size_t)grid * KW * tile_bytes > workspace_bytes) grid = (long long)(workspace_bytes / (KW * tile_bytes));
     if (grid < 1) return ERF_EUNSUPPORTED;
-    p.partial = workspace;
     auto kern = wgrad1d_kernel<C, CG, KW, CPW, M, KIX, KIZ, OCC>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ERF_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3((int)grid), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((int)grid, count), dim3(NW * 64), lds, stream, tab);
     int rc = erf_check_launch();
     if (rc) return rc;
-    return wgrad_reduce_launch(workspace, (int)grid * KW, C, 3 * C, C, map, dw, stream);
+    for (int i = 0; i < count; ++i) {
+        if (descs) wgrad_reduce_defer(&descs[i]);
+        rc = wgrad_reduce_launch(jobs[i].workspace, (int)grid * KW, C, 3 * C, C, maps[i], jobs[i].dw, stream);
+        if (descs) wgrad_reduce_defer(nullptr);
+        if (rc) return rc;
+    }
+    return ERF_OK;
+}
+
+int wgrad1d_many_launch(const W1dJob* jobs, int count, int dtype, int N, int H, int W, int C, const PackParams* maps,
+                        size_t workspace_bytes, WgradReduceDesc* descs, hipStream_t stream) {
+    if (dtype != 1) return ERF_EUNSUPPORTED;
+    static const int off = getenv("ERF_WGRAD1D_OFF") ? atoi(getenv("ERF_WGRAD1D_OFF")) : 0;
+    if (off) return ERF_EUNSUPPORTED;
+    if (C == 128) return launch_w1d<128, 8, 1, 3, 128, 6, 4>(jobs, count, N, H, W, maps, workspace_bytes, descs, stream);
+    if (C == 64) return launch_w1d<64, 4, 1, 3, 128, 5, 4>(jobs, count, N, H, W, maps, workspace_bytes, descs, stream);
+    if (C == 16) return launch_w1d<16, 1, 4, 3, 512, 5, 4>(jobs, count, N, H, W, maps, workspace_bytes, descs, stream);
+    return ERF_EUNSUPPORTED;
 }
 
 int wgrad1d_launch(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis, int dilation,
                    const PackParams& map, float* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (dtype != 1) return ERF_EUNSUPPORTED;
-    static const int off = getenv("ERF_WGRAD1D_OFF") ? atoi(getenv("ERF_WGRAD1D_OFF")) : 0;
-    if (off) return ERF_EUNSUPPORTED;
-    W1dParams p{};
-    p.x = x; p.dz = dz; p.d = dilation;
-    if (C == 128) return launch_w1d<128, 8, 1, 3, 128, 6, 4>(p, N, H, W, axis, map, dw, workspace, workspace_bytes, stream);
-    if (C == 64) return launch_w1d<64, 4, 1, 3, 128, 5, 4>(p, N, H, W, axis, map, dw, workspace, workspace_bytes, stream);
-    if (C == 16) return launch_w1d<16, 1, 4, 3, 512, 5, 4>(p, N, H, W, axis, map, dw, workspace, workspace_bytes, stream);
-    return ERF_EUNSUPPORTED;
+    const W1dJob job{x, dz, dw, workspace, axis, dilation};
+    return wgrad1d_many_launch(&job, 1, dtype, N, H, W, C, &map, workspace_bytes, nullptr, stream);
 }

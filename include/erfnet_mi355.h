@@ -278,6 +278,14 @@ size_t erf_wgrad_reduce_desc_bytes(void);
 int erf_conv1d_wgrad_partial(const void* x, const void* dz, float* dw, int dtype, int N, int H, int W, int C, int axis,
                              int dilation, void* workspace, size_t workspace_bytes, void* desc, void* stream);
 int erf_wgrad_reduce_many(const void* table, int count, void* stream);
+/* The same for up to 4 convolutions on tensors of one shape [N, H, W, C] -- the four factorized convolutions of a
+ * non_bottleneck_1d block (train/erfnet.py:44-58) -- as ONE contraction launch: each layer gets a share of the chip and
+ * proportionally fewer partial tiles.  Every job brings its own workspace of `workspace_bytes`
+ * (erf_wgrad_workspace_bytes(C, C, 3, N*H*W)); descs: count * erf_wgrad_reduce_desc_bytes() of host memory.
+ * ERF_EUNSUPPORTED (fp32, other channel counts): nothing was launched, use erf_conv1d_wgrad_partial per layer. */
+typedef struct erf_wgrad_job { const void* x; const void* dz; float* dw; void* workspace; int axis; int dilation; } erf_wgrad_job;
+int erf_conv1d_wgrad_partial_many(const erf_wgrad_job* jobs, int count, int dtype, int N, int H, int W, int C,
+                                  size_t workspace_bytes, void* descs, void* stream);
 int erf_image_to_nhwc_padded(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, void* stream);
 int erf_stem_wgrad(const void* x_pad, const void* dz, float* dw, int dtype, int N, int Hin, int Win, void* workspace,
                    size_t workspace_bytes, void* stream);
