@@ -307,11 +307,12 @@ static int launch_w1d(const W1dJob* jobs, int count, int N, int H, int W, const 
         ntiles_min = p.ntiles < ntiles_min ? p.ntiles : ntiles_min;
     }
     for (int i = count; i < ERF_W1D_MAX; ++i) tab.p[i] = tab.p[0];
-    // one layer alone: 128 workgroups per unit of occupancy (more only adds partial tiles); several layers share twice that
+    // one layer alone: 128 workgroups per unit of occupancy (more only adds partial tiles); several layers share one
+    // workgroup per CU (measured at 128 / 256 / 512 / 768 / 1024 in all: 256 is the fastest for every channel count)
     static const int want = getenv("ERF_WGRAD1D_WGS") ? atoi(getenv("ERF_WGRAD1D_WGS")) : 128;
     static const int want_many = getenv("ERF_WGRAD1D_WGS_MANY") ? atoi(getenv("ERF_WGRAD1D_WGS_MANY")) : 256;
     const size_t tile_bytes = (size_t)C * 3 * C * sizeof(float);
-    long long grid = count == 1 ? (long long)want * OCC : (long long)want_many * OCC / count;
+    long long grid = count == 1 ? (long long)want * OCC : (long long)want_many / count;
     if (grid > ntiles_min) grid = ntiles_min;
     if ((size_t)grid * KW * tile_bytes > workspace_bytes) grid = (long long)(workspace_bytes / (KW * tile_bytes));
     if (grid < 1) return ERF_EUNSUPPORTED;
