@@ -1,0 +1,126 @@
+"""The data-parallel Trainer with real kernels and two ranks.
+
+Two processes share the one GPU of the test box and talk through gloo (RCCL refuses two ranks on one device); everything
+else is the production path: gradient sinks, the three bucket all-reduces hung on the backward pass, deferred bias /
+weight-gradient reductions flushed before a bucket leaves, the global-denominator loss, the fused Adam.  Expected values:
+nn.DataParallel's semantics (train/main.py:196-204, :543) composed in ONE process from the library's own differentiable
+modules -- each shard through the model with its own BatchNorm batch statistics, one weighted loss over both shards'
+logits, gradients summed.
+"""
+import os
+import queue
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from erfnet_pytorch_amd import synthetic as S
+from oracle import erfnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+H, W, NC, NB = 64, 128, 20, 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(dtype):
+    from erfnet_pytorch_amd import erfnet as E
+    m = E.ERFNet(NC)
+    m.load_state_dict(O.synthetic_state(O.erfnet_template(NC)))
+    m = m.to("cuda:0").train()
+    m.compute_dtype = torch.bfloat16 if dtype == "bf16" else None
+    for mod in m.modules():
+        if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
+            mod.__dict__["_erf_forced_mask"] = torch.ones(NB, mod.conv3x1_1.out_channels)       # dropout off: deterministic
+    return m
+
+
+def _shard(rank):
+    x = S.synthetic_images(NB, H, W, seed=170 + rank).to("cuda:0")
+    t = S.synthetic_labels(NB, H, W, NC, seed=170 + rank, ignore_frac=0.05 + 0.3 * rank).to("cuda:0")   # unequal weight sums
+    return x, t
+
+
+def _worker(rank, world, port, dtype, overlap, q):
+    import torch.distributed as dist
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        m = _build(dtype)
+        tr = Trainer(m, CITYSCAPES_WEIGHTS, group=dist.group.WORLD, world_size=world, overlap=overlap)
+        x, t = _shard(rank)
+        loss, _ = tr.step(x, t)
+        torch.cuda.synchronize()
+        q.put((rank, float(loss), tr.gflat.cpu().numpy().copy(), tr.flat.cpu().numpy().copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, dtype, overlap):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r = q.get(timeout=90)
+            got[r[0]] = r[1:]
+    except queue.Empty:
+        pass
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+            p.join()
+    assert len(got) == world and all(p.exitcode == 0 for p in procs), "the ranks did not complete"
+    return got
+
+
+@pytest.mark.parametrize("dtype,overlap,tol", [("bf16", True, 8e-2), ("bf16", False, 8e-2), ("fp32", True, 1e-4)])
+def test_two_rank_trainer_step_equals_dataparallel_semantics(dtype, overlap, tol):
+    from erfnet_pytorch_amd.loss import CrossEntropyLoss2d
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    world = 2
+    got = _run(world, dtype, overlap)
+    # replicas stay identical: same reduced gradients, same parameters after Adam, same (global) loss
+    assert got[0][0] == got[1][0]
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+
+    # one process: both shards through one set of parameters, per-shard BatchNorm statistics, one loss, summed gradients
+    m = _build(dtype)
+    outs, tgts = [], []
+    for r in range(world):
+        x, t = _shard(r)
+        outs.append(m(x))
+        tgts.append(t[:, 0])
+    w = torch.tensor(CITYSCAPES_WEIGHTS, device="cuda:0")
+    loss = CrossEntropyLoss2d(w)(torch.cat(outs), torch.cat(tgts))
+    loss.backward()
+    assert abs(got[0][0] - loss.item()) <= (1e-5 if dtype == "fp32" else 2e-3) * abs(loss.item())
+    ref = Trainer(_build(dtype), CITYSCAPES_WEIGHTS)            # only for the arena's name -> offset map
+    gflat = torch.from_numpy(got[0][1])
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        o, n = ref.offsets[k]
+        g = gflat[o:o + n].view_as(p)
+        pg = p.grad.detach().cpu()
+        if ".bias" in k and "bn" not in k and "output_conv" not in k and pg.abs().max() < 1e-3 * gflat.abs().max():
+            continue                                             # conv bias in front of a batch-statistics BatchNorm: exactly 0 here, rounding noise there
+        err = (g - pg).norm().item() / max(pg.norm().item(), 1e-12)
+        worst = max(worst, err)
+        assert err <= tol, (k, err)

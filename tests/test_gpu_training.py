@@ -524,7 +524,8 @@ def test_trainer_checkpoint_resume_is_interchangeable_with_torch_adam():
     assert trb.step_count == 2
 
 
-@pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 28),
+@pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 18),      # fp32: the 128-channel layers keep the separate BatchNorm backward
+                                                      
                                                       (torch.bfloat16, 8e-2, (1, 512, 1024), 34)])
 def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, expected):
     """The BatchNorm backward whose reductions ride in the preceding data-gradient convolution (in-block bn1, and the
