@@ -65,8 +65,21 @@ def dist_setup(n_gpus):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("ERF_BENCH_REHEARSAL") == "1":
+            # rehearsal of the multi-rank code path on a box with ONE GPU: every rank on device 0, gloo instead of RCCL
+            # (RCCL refuses two ranks on one device), collectives on device tensors staged through host copies made
+            # here (gloo's own device-tensor path stalled at full size with two busy processes on one GPU).  The
+            # numbers of such a run mean nothing; the JSON line says so.
+            import faulthandler
+            faulthandler.dump_traceback_later(int(os.environ.get("ERF_BENCH_REHEARSAL_LIMIT", "90")), exit=True)
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+            from erfnet_pytorch_amd.dp import stage_collectives_through_host
+            stage_collectives_through_host()
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -326,6 +339,8 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.mode != "multi":
             res["cpu_baseline"] = cpu_baseline(args.height, args.width)
+        if os.environ.get("ERF_BENCH_REHEARSAL") == "1" and world > 1:
+            res["data"] = "synthetic; REHEARSAL: all ranks share one GPU over gloo, not a measurement"
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -486,8 +486,7 @@ static int launch_buf(BufParams p, int N, int H, int W, int axis, int* groups, h
         if (!p.stats || !post || !p.bmean || !p.binvstd) return ERF_EINVAL;
         if (p.bmask && axis != 0) return ERF_EUNSUPPORTED;       // the mask is per image: tiles must not mix images
         // fp32 at 128 channels does not fit the register file with the BatchNorm-backward epilogue (216 bytes of scratch
-        // per lane); that instance is not built -- the caller runs the BatchNorm backward as its own pass.  (With two
-        // processes sharing one GPU a launch of it never completed, and a spilling kernel is no gain anyway.)
+        // per lane); that instance is not built -- the caller runs the BatchNorm backward as its own pass.
         if constexpr (sizeof(T) == 4 && C == 128) return ERF_EUNSUPPORTED;
         else ERF_LAUNCH_BUF(true, 2)
     } else if (p.stats) { if (post) ERF_LAUNCH_BUF(true, 1) else ERF_LAUNCH_BUF(false, 1) }

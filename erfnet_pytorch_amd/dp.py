@@ -60,3 +60,29 @@ def bucket_ranges(offsets, only_encode: bool = False) -> Tuple[List[Tuple[int, i
     if only_encode:
         return [(enc128[0], head[1]), enc_lo], [(enc_lo[0], head[1])]
     return [decoder, enc128, enc_lo], [(enc_lo[0], enc128[1]), decoder]
+
+
+def stage_collectives_through_host():
+    """Rehearsal / test aid for boxes where several ranks share ONE GPU (gloo backend): torch.distributed.all_reduce on a
+    device tensor is replaced by copy-to-host, all-reduce, copy-back, done synchronously by the caller.  The algorithm
+    around the collectives (which ranges are reduced, when, with what result) stays what it is; only the transport changes.
+    Never used on the RCCL path."""
+    import torch.distributed as dist
+    if getattr(dist.all_reduce, "_erf_staged", False):
+        return
+    orig = dist.all_reduce
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def staged(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        if not t.is_cuda:
+            return orig(t, op=op, group=group, async_op=async_op)
+        h = t.detach().cpu()
+        orig(h, op=op, group=group)
+        t.copy_(h)
+        return _Done() if async_op else None
+
+    staged._erf_staged = True
+    dist.all_reduce = staged

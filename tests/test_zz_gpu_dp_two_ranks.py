@@ -1,7 +1,7 @@
 """The data-parallel Trainer with real kernels and two ranks.
 
-Two processes share the one GPU of the test box and talk through gloo (RCCL refuses two ranks on one device); everything
-else is the production path: gradient sinks, the three bucket all-reduces hung on the backward pass, deferred bias /
+Two processes share the one GPU of the test box and talk through gloo (RCCL refuses two ranks on one device), with the
+collectives staged through host copies (dp.stage_collectives_through_host); everything else is the production path: gradient sinks, the three bucket all-reduces hung on the backward pass, deferred bias /
 weight-gradient reductions flushed before a bucket leaves, the global-denominator loss, the fused Adam.  Expected values:
 nn.DataParallel's semantics (train/main.py:196-204, :543) composed in ONE process from the library's own differentiable
 modules -- each shard through the model with its own BatchNorm batch statistics, one weighted loss over both shards'
@@ -52,6 +52,8 @@ def _worker(rank, world, port, dtype, overlap, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from erfnet_pytorch_amd.dp import stage_collectives_through_host
+    stage_collectives_through_host()          # gloo's device-tensor path stalls when two busy processes share one GPU
     try:
         torch.cuda.set_device(0)
         m = _build(dtype)
