@@ -125,6 +125,7 @@ SIGNATURES = {
     "erf_convT2x2s2_pack": (I, [P, P, I, I, I, P]),
     "erf_convT2x2s2": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "erf_spatial_mean": (I, [P, I, P, I, I, I, I, P]),
+    "erf_concat_channels": (I, [P, I, P, I, P, I, I, I, I, P]),
     "erf_image_to_nhwc_channels": (I, [P, I, P, I, I, I, I, I, P]),
     "erf_pointwise_grad_channels": (I, [I]),
     "erf_pointwise_grad_nhwc": (I, [P, I, P, I, I, I, I, I, P]),

@@ -312,6 +312,11 @@ int erf_spatial_mean(const void* x, int dtype, float* feat, int N, int H, int W,
     return spatial_mean_launch(x, dtype, feat, N, (long long)H * W, C, (hipStream_t)stream);
 }
 
+int erf_concat_channels(const void* a, int Ca, const void* b, int Cb, void* out, int dtype, int N, int H, int W, void* stream) {
+    if (!a || !b || !out || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0) return ERF_EINVAL;
+    return concat_channels_launch(a, Ca, b, Cb, out, dtype, (long long)N * H * W, (hipStream_t)stream);
+}
+
 int erf_image_to_nhwc_channels(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, int cpad, void* stream) {
     if (!x_nchw || !out || !dtype_ok(dtype) || !dtype_ok(x_dtype) || N <= 0 || cpad < 3) return ERF_EINVAL;
     return image_pad_launch(x_nchw, x_dtype, out, dtype, N, (long long)H * W, cpad, (hipStream_t)stream);

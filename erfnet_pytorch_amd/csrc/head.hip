@@ -24,25 +24,70 @@ __global__ __launch_bounds__(256) void pool_mean_fwd_kernel(const T* __restrict_
 
 // feat[n][c] = mean over all H x W positions (fp32 output)
 template <typename T>
-__global__ __launch_bounds__(256) void spatial_mean_kernel(const T* __restrict__ x, float* __restrict__ feat, int N, long long HW, int C) {
-    // one block per image, thread t owns channels t, t + 256, ...; rows of C channels are read coalesced
+__global__ __launch_bounds__(1024) void spatial_mean_kernel(const T* __restrict__ x, float* __restrict__ feat, int N, long long HW, int C) {
+    // one block per image; the block's threads form 1024 / C slices of the pixel range x C channels (rows of C channels
+    // are read coalesced), and the slices of a channel meet in LDS in slice order: the sum's order is fixed
+    __shared__ float part[1024];
     const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const T* p = x + (long long)n * HW * C + c;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        long long i = 0;
-        for (; i + 3 < HW; i += 4) {
-            s0 += Elem<T>::ld(p + i * C); s1 += Elem<T>::ld(p + (i + 1) * C);
-            s2 += Elem<T>::ld(p + (i + 2) * C); s3 += Elem<T>::ld(p + (i + 3) * C);
+    const int nsl = C <= 1024 ? 1024 / C : 1;
+    const int sl = threadIdx.x / C;
+    const long long per = (HW + nsl - 1) / nsl;
+    for (int c0 = 0; c0 < C; c0 += 1024) {
+        const int c = c0 + (C <= 1024 ? (int)threadIdx.x % C : (int)threadIdx.x);
+        float acc = 0.f;
+        if (sl < nsl && c < C) {
+            const T* p = x + (long long)n * HW * C + c;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            long long i = sl * per;
+            const long long i1 = i + per < HW ? i + per : HW;
+            for (; i + 3 < i1; i += 4) {
+                s0 += Elem<T>::ld(p + i * C); s1 += Elem<T>::ld(p + (i + 1) * C);
+                s2 += Elem<T>::ld(p + (i + 2) * C); s3 += Elem<T>::ld(p + (i + 3) * C);
+            }
+            for (; i < i1; ++i) s0 += Elem<T>::ld(p + i * C);
+            acc = (s0 + s1) + (s2 + s3);
         }
-        for (; i < HW; ++i) s0 += Elem<T>::ld(p + i * C);
-        feat[n * C + c] = ((s0 + s1) + (s2 + s3)) / (float)HW;
+        if (nsl == 1) {
+            if (c < C) feat[n * C + c] = acc / (float)HW;
+            continue;
+        }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            float s = 0.f;
+            for (int k = 0; k < nsl; ++k) s += part[k * C + threadIdx.x];
+            feat[n * C + threadIdx.x] = s / (float)HW;
+        }
+        __syncthreads();
     }
 }
 
 int spatial_mean_launch(const void* x, int dtype, float* feat, int N, long long HW, int C, hipStream_t stream) {
-    if (dtype == 1) hipLaunchKernelGGL(spatial_mean_kernel<bf16raw>, dim3(N), dim3(256), 0, stream, (const bf16raw*)x, feat, N, HW, C);
-    else hipLaunchKernelGGL(spatial_mean_kernel<float>, dim3(N), dim3(256), 0, stream, (const float*)x, feat, N, HW, C);
+    if (dtype == 1) hipLaunchKernelGGL(spatial_mean_kernel<bf16raw>, dim3(N), dim3(1024), 0, stream, (const bf16raw*)x, feat, N, HW, C);
+    else hipLaunchKernelGGL(spatial_mean_kernel<float>, dim3(N), dim3(1024), 0, stream, (const float*)x, feat, N, HW, C);
+    return erf_check_launch();
+}
+
+// out[p][0:Ca] = a[p][:], out[p][Ca:Ca+Cb] = b[p][:] for NHWC maps, in 16-byte chunks (the decoders' skip concatenation)
+__global__ __launch_bounds__(256) void concat_channels_kernel(const i32x4* __restrict__ a, const i32x4* __restrict__ b,
+                                                              i32x4* __restrict__ out, long long pixels, int cha, int chb) {
+    const int ch = cha + chb;
+    const long long total = pixels * ch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / ch;
+        const int k = (int)(i - p * ch);
+        out[i] = k < cha ? a[p * cha + k] : b[p * chb + (k - cha)];
+    }
+}
+
+int concat_channels_launch(const void* a, int Ca, const void* b, int Cb, void* out, int dtype, long long pixels, hipStream_t stream) {
+    const int epc = dtype == 1 ? 8 : 4;
+    if (Ca % epc || Cb % epc) return ERF_EUNSUPPORTED;
+    const long long total = pixels * ((Ca + Cb) / epc);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(concat_channels_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const i32x4*)a, (const i32x4*)b,
+                       (i32x4*)out, pixels, Ca / epc, Cb / epc);
     return erf_check_launch();
 }
 

@@ -67,6 +67,7 @@ int wgrad1d_many_launch(const W1dJob* jobs, int count, int dtype, int N, int H, 
                         size_t workspace_bytes, WgradReduceDesc* descs, hipStream_t stream);
 
 // ---- classifier head of the ImageNet variant (head.hip)
+int concat_channels_launch(const void* a, int Ca, const void* b, int Cb, void* out, int dtype, long long pixels, hipStream_t stream);
 int spatial_mean_launch(const void* x, int dtype, float* feat, int N, long long HW, int C, hipStream_t stream);
 int pool_mean_fwd_launch(const void* x, int dtype, float* feat, int N, int H, int W, int C, hipStream_t stream);
 int pool_mean_bwd_launch(const void* x, const float* dfeat, void* dx, int dtype, int N, int H, int W, int C, hipStream_t stream);

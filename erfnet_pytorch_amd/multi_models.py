@@ -21,6 +21,15 @@ __all__ = ["DownsamplerBlock_simplified", "non_bottleneck_1d", "Encoder", "Upsam
            "Decoder_depth", "Classifier", "Multi_models"]
 
 
+def _concat(a, b):
+    """torch.cat([a, b], 1) of the reference on NHWC maps of one dtype."""
+    n, h, w, ca = a.shape
+    cb = b.shape[3]
+    out = torch.empty((n, h, w, ca + cb), dtype=a.dtype, device=a.device)
+    call("erf_concat_channels", a.data_ptr(), ca, b.data_ptr(), cb, out.data_ptr(), ops.dt(a), n, h, w, _stream())
+    return out
+
+
 def _stream():
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
@@ -160,10 +169,10 @@ class _SkipDecoder(nn.Module):
     def forward_nhwc(self, x, s1, s2, out_f32=True):
         for layer in self.upblock_1:
             x = layer.forward_nhwc(x)
-        x = torch.cat([x, s2], dim=3)                       # channel concat of NHWC maps (multi_models.py:141)
+        x = _concat(x, s2)                                  # channel concat of NHWC maps (multi_models.py:141)
         for layer in self.upblock_2:
             x = layer.forward_nhwc(x)
-        x = torch.cat([x, s1], dim=3)                       # multi_models.py:145
+        x = _concat(x, s1)                                  # multi_models.py:145
         n, h, w, _ = x.shape
         nc = self.upblock_3[0].out_channels
         packed, bias = self._head(ops.dt(x))

@@ -206,7 +206,9 @@ int erf_pack_replay(const void* table_dev, int count, long long max_chunks, int 
  *   DownsamplerBlock_simplified.forward (multi_models.py:31-36) in one pass.
  * erf_convT2x2s2: ConvTranspose2d(32, Cout, 2, stride 2) + bias -> NCHW planes (the decoders' last layer,
  *   multi_models.py:134 / :165), weights [32][Cout][2][2].
- * erf_spatial_mean: feat[n][c] = mean over H x W (Classifier.forward `output.mean(3).mean(2)`, multi_models.py:200). */
+ * erf_spatial_mean: feat[n][c] = mean over H x W (Classifier.forward `output.mean(3).mean(2)`, multi_models.py:200).
+ * erf_concat_channels: out[n][h][w][:] = a[n][h][w][:] ++ b[n][h][w][:] -- `torch.cat([output, skip], 1)` of the decoders
+ *   (multi_models.py:141,145) on NHWC maps; Ca and Cb multiples of 8 (bf16) / 4 (fp32), else ERF_EUNSUPPORTED. */
 size_t erf_conv3x3_packed_bytes(int dtype, int Cin, int Cout);
 int erf_conv3x3_pack(const float* w, void* packed, int dtype, int Cin, int Cin_valid, int Cout, void* stream);
 int erf_conv3x3(const void* x, void* y, const void* packed, const float* scale, const float* shift, int dtype, int N, int Hin,
@@ -218,6 +220,7 @@ int erf_convT2x2s2_pack(const float* w, void* packed, int dtype, int Cin, int Co
 int erf_convT2x2s2(const void* x, void* y, const void* packed, const float* bias, int out_f32, int dtype, int N, int Hin, int Win,
                    int Cin, int Cout, void* stream);
 int erf_spatial_mean(const void* x, int dtype, float* feat, int N, int H, int W, int C, void* stream);
+int erf_concat_channels(const void* a, int Ca, const void* b, int Cb, void* out, int dtype, int N, int H, int W, void* stream);
 int erf_image_to_nhwc_channels(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, int cpad, void* stream);
 
 /* ---- data gradients (autograd of the layers above) --------------------------------------
