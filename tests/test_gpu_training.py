@@ -575,16 +575,18 @@ def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, exp
         assert err <= tol, (k, err)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 8e-2)])
-def test_fused_output_head_and_loss_equals_separate_kernels(dtype, tol):
+@pytest.mark.parametrize("dtype,tol,shape", [(torch.float32, 1e-4, (2, 128, 256)), (torch.bfloat16, 8e-2, (2, 128, 256)),
+                                             (torch.float32, 1e-4, (1, 48, 80)), (torch.bfloat16, 8e-2, (3, 40, 24))])
+def test_fused_output_head_and_loss_equals_separate_kernels(dtype, tol, shape):
     """Trainer(fused_head_loss=True): Decoder.output_conv + weighted CE with the logits kept in registers gives the loss and
     the gradients of the separate output_conv / CrossEntropyLoss2d / patch kernels (fp32: summation order only; bf16: the
     rounding of d logits to bf16 happens at the same place, the rest is the backward pass's usual bf16 spread)."""
     from erfnet_pytorch_amd import erfnet as E
     from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
     sd = O.synthetic_state(O.erfnet_template(20))
-    x = S.synthetic_images(2, 128, 256, seed=95).to(DEV)
-    t = S.synthetic_labels(2, 128, 256, 20, seed=95).to(DEV)
+    nb, hh, ww = shape                              # the small shapes leave the head kernel's last workgroup partly empty
+    x = S.synthetic_images(nb, hh, ww, seed=95).to(DEV)
+    t = S.synthetic_labels(nb, hh, ww, 20, seed=95).to(DEV)
 
     def run(fused):
         m = E.ERFNet(20)
@@ -593,7 +595,7 @@ def test_fused_output_head_and_loss_equals_separate_kernels(dtype, tol):
         m.compute_dtype = torch.bfloat16 if dtype == torch.bfloat16 else None
         for mod in m.modules():
             if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
-                mod.__dict__["_erf_forced_mask"] = torch.ones(2, mod.conv3x1_1.out_channels)
+                mod.__dict__["_erf_forced_mask"] = torch.ones(nb, mod.conv3x1_1.out_channels)
         tr = Trainer(m, CITYSCAPES_WEIGHTS, fused_head_loss=fused)
         loss, out = tr.step(x, t)
         assert (out is None) == fused
@@ -680,3 +682,39 @@ def test_checkpoint_file_round_trip_through_reference_format(tmp_path):
     a.eval(); b.eval()
     with torch.no_grad():
         assert torch.equal(a(x), b(x))
+
+
+@pytest.mark.parametrize("nc", [3, 6, 20, 32])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_fused_head_loss_primitive_vs_torch(nc, dtype, tol):
+    """ConvTranspose2d(16, nc, 2, stride 2) + weighted cross entropy as one autograd node (train/erfnet.py:171,179 +
+    train/main.py:121,202) against torch's own two ops in fp32: loss, d input, d weight, d bias; every class-count tile
+    variant, labels outside [0, nc) and zero-weight classes included."""
+    from erfnet_pytorch_amd import autograd as ag
+    g = torch.Generator().manual_seed(7 + nc)
+    n, h, w = 2, 12, 20                                               # 480 input pixels: the last workgroup is partly empty
+    x = torch.randn(n, 16, h, w, generator=g)
+    wt = torch.randn(16, nc, 2, 2, generator=g) * 0.3
+    b = torch.randn(nc, generator=g) * 0.1
+    cw = torch.rand(nc, generator=g) + 0.5
+    cw[nc - 1] = 0.0                                                  # the reference's weight[19] = 0
+    t = torch.randint(0, nc, (n, 2 * h, 2 * w), generator=g)
+    t[0, :3, :5] = 255                                                # ignored by value
+    xr = x.to(dtype).float().requires_grad_(True)                     # the same rounded input on both sides
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    logits = torch.nn.functional.conv_transpose2d(xr, wr.to(dtype).float() if dtype == torch.bfloat16 else wr, br, stride=2)
+    valid = (t >= 0) & (t < nc)
+    tt = torch.where(valid, t, torch.zeros_like(t))
+    nll = torch.nn.functional.cross_entropy(logits, tt, reduction="none")
+    wv = cw[tt] * valid
+    ref = (nll * wv).sum() / wv.sum()
+    ref.backward()
+
+    xd = x.to(DEV).to(dtype).detach().requires_grad_(True)
+    wd, bd = wt.to(DEV).detach().requires_grad_(True), b.to(DEV).detach().requires_grad_(True)
+    loss = ag._HeadLossFn.apply(xd, wd, bd, t.to(DEV), cw.to(DEV), None, None)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= (1e-5 if dtype == torch.float32 else 2e-3) * abs(ref.item())
+    assert rel_err(xd.grad.float().cpu(), xr.grad) <= tol
+    assert rel_err(wd.grad.cpu(), wr.grad) <= tol
+    assert rel_err(bd.grad.cpu(), br.grad) <= tol
