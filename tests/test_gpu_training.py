@@ -151,6 +151,34 @@ def test_conv1d_dgrad_wgrad_primitives(dtype, tol, c, shape, axis, dil):
     assert rel_err(dw.cpu(), wr.grad) <= (1e-5 if dtype == torch.float32 else 1e-5)      # operands identical: fp32 sums
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c,shape,dil", [(128, (2, 128, 16, 24), 4), (64, (2, 64, 24, 40), 1), (16, (1, 16, 40, 56), 1), (128, (1, 128, 40, 40), 16)])
+def test_block_weight_gradients_in_one_launch(dtype, c, shape, dil):
+    """The four weight gradients of a non_bottleneck_1d block (axes H, W, dilations 1 and d) through
+    erf_conv1d_wgrad_partial_many (bf16; fp32 takes the per-layer path behind the same call) against torch-CPU autograd
+    on identical pre-rounded operands, each layer with its own operands."""
+    import torch.nn.functional as F
+    from erfnet_pytorch_amd import autograd as ag
+    rnd = lambda t: t.to(dtype).float()
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    jobs, refs = [], []
+    for k, (axis, d) in enumerate([(1, dil), (0, dil), (1, 1), (0, 1)]):
+        seed = 900 + 10 * k + c
+        x = rnd(activations(shape, seed) - 0.3)
+        dz = rnd(upstream(shape, seed + 1))
+        kshape = (c, c, 3, 1) if axis == 0 else (c, c, 1, 3)
+        wr = torch.zeros(kshape).requires_grad_(True)
+        pad, dl = ((d, 0), (d, 1)) if axis == 0 else ((0, d), (1, d))
+        F.conv2d(x, wr, None, padding=pad, dilation=dl).backward(dz)
+        dw = torch.full(kshape, float("nan"), device=DEV)
+        jobs.append((nh(x), nh(dz), dw, axis, d))
+        refs.append(wr.grad)
+    ag.conv1d_wgrad_block(jobs)
+    ag.flush_bias_sums()
+    for (_, _, dw, _, _), ref in zip(jobs, refs):
+        assert rel_err(dw.cpu(), ref) <= 1e-5
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 8e-3)])
 def test_batchnorm_primitives(dtype, tol):
     import torch.nn.functional as F
