@@ -536,18 +536,30 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ z, const 
     }
 }
 
-__global__ void ce_finalize_kernel(const float* __restrict__ partials, int groups, float* __restrict__ out) {
-    // 64 threads: lane l sums groups l, l + 64, ... in double, then a fixed-order butterfly
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restrict__ partials, int groups, float* __restrict__ out) {
+    // 1024 threads: thread t sums groups t, t + 1024, ... in double; a fixed-order butterfly per wave, then the 16 waves
+    // meet in LDS in wave order
+    __shared__ double sh[16][2];
     double a = 0, b = 0;
-    for (int g = threadIdx.x; g < groups; g += 64) { a += partials[2 * g]; b += partials[2 * g + 1]; }
+    for (int g = threadIdx.x; g < groups; g += 1024) {
+        const float2 v = *(const float2*)(partials + 2 * g);
+        a += v.x; b += v.y;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    if (threadIdx.x == 0) { out[0] = (float)a; out[1] = (float)b; out[2] = (float)(a / b); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = a; sh[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0; b = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { a += sh[w][0]; b += sh[w][1]; }
+        out[0] = (float)a; out[1] = (float)b; out[2] = (float)(a / b);
+    }
 }
 
 int ce_partials_finalize_launch(const float* partials, long long groups, float* out3, hipStream_t stream) {
     if (groups <= 0 || groups > 0x7FFFFFFFLL) return ERF_EINVAL;
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, (int)groups, out3);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, (int)groups, out3);
     return erf_check_launch();
 }
 
@@ -565,7 +577,7 @@ int ce_fwd_launch(const void* z, int dtype, const long long* target, const float
     if (dtype == 1) { if (C == 20) CE_FWD(bf16raw, 20); else if (C == 6) CE_FWD(bf16raw, 6); else CE_FWD(bf16raw, 0); }
     else { if (C == 20) CE_FWD(float, 20); else if (C == 6) CE_FWD(float, 6); else CE_FWD(float, 0); }
 #undef CE_FWD
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, stream, partials, (int)g, out);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, (int)g, out);
     return erf_check_launch();
 }
 
