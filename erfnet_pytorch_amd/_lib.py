@@ -57,6 +57,8 @@ SIGNATURES = {
     "erf_wgrad_reduce_desc_bytes": (c_size_t, []),
     "erf_conv1d_wgrad_partial": (I, [P, P, P, I, I, I, I, I, I, I, P, c_size_t, P, P]),
     "erf_wgrad_reduce_many": (I, [P, I, P]),
+    "erf_wgrad_reduce_record_begin": (I, [P, I]),
+    "erf_wgrad_reduce_record_end": (I, []),
     "erf_conv1d_wgrad_partial_many": (I, [P, I, I, I, I, I, I, c_size_t, P, P]),
     "erf_conv1d_dgrad_bias_partial": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P, P]),
     "erf_channel_sum_finalize_many": (I, [P, I, P]),

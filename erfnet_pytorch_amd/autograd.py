@@ -298,6 +298,23 @@ def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None, defer=False):
     return dw
 
 
+def wgrad_deferred(dev, keep, fn, *args):
+    """call(fn, *args) for a weight-gradient entry point, with its partial-sum reductions left pending: dW is complete
+    after flush_bias_sums().  `keep`: what must stay alive until then (workspace, dW)."""
+    dsz = size_query("erf_wgrad_reduce_desc_bytes")
+    descs = torch.zeros(4 * dsz, dtype=torch.uint8)
+    call("erf_wgrad_reduce_record_begin", descs.data_ptr(), 4)
+    try:
+        call(fn, *args)
+    finally:
+        n = query("erf_wgrad_reduce_record_end")
+    if n:
+        with _PENDING_LOCK:
+            pend = _PENDING_WGRAD.setdefault(dev.index, [])
+            for i in range(n):
+                pend.append((descs[i * dsz:(i + 1) * dsz], 0, keep))
+
+
 def conv1d_wgrad_block(jobs):
     """dW of several factorized convolutions on tensors of one shape -- jobs: (x, dz, dw_out, axis, dilation) -- by one
     contraction launch where the library takes the shape (bf16, C in {16, 64, 128}), else layer by layer.  Complete after
@@ -491,13 +508,13 @@ class _DownFn(torch.autograd.Function):
             call("erf_image_to_nhwc_padded", xh.data_ptr(), ops.dt(xh), xpad.data_ptr(), code, n, 2 * ho, 2 * wo, _stream())
             nb = size_query("erf_wgrad_workspace_bytes", 13, cpad, 9, n * ho * wo)
             ws = _ws(nb, dev)
-            call("erf_stem_wgrad", xpad.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, ws.data_ptr(), nb,
-                 _stream())
+            wgrad_deferred(dev, (ws, dw, xpad), "erf_stem_wgrad", xpad.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho,
+                           2 * wo, ws.data_ptr(), nb, _stream())
             return (None, None) + sk.ret(dw, db, dgamma, dbeta)
         nb = size_query("erf_wgrad_workspace_bytes", cc, cin, 9, n * ho * wo)
         ws = _ws(nb, dev)
-        call("erf_downsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho, 2 * wo, cin, cout,
-             ws.data_ptr(), nb, _stream())
+        wgrad_deferred(dev, (ws, dw), "erf_downsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho,
+                       2 * wo, cin, cout, ws.data_ptr(), nb, _stream())
         dx = None
         if ctx.need_dx:
             pk = ops.packed_generic(ctx.mod, "dgrad", w, code,
@@ -541,10 +558,10 @@ class _UpFn(torch.autograd.Function):
                                                dgamma=sk.out("bn.weight", (cout,), dev), dbeta=sk.out("bn.bias", (cout,), dev))
         db = pre_bn_bias_grad(dz, ctx.training, sk.out("conv.bias", (cout,), dev), sk.zeroed)
         dw = sk.out("conv.weight", w.shape, dev)
-        nb = size_query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)
+        nb = 4 * size_query("erf_wgrad_workspace_bytes", cout, cin, 4, n * h * wd)      # a slice per output phase
         ws = _ws(nb, dev)
-        call("erf_upsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, cout, ws.data_ptr(), nb,
-             _stream())
+        wgrad_deferred(dev, (ws, dw), "erf_upsampler_wgrad", xh.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, cout,
+                       ws.data_ptr(), nb, _stream())
         pk = ops.packed_generic(ctx.mod, "dgrad", w, code, lambda: _pack_now("erf_upsampler_dgrad", w, code, dev, cin, cout))
         dxh = torch.empty_like(xh)
         call("erf_upsampler_dgrad", dz.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, cin, cout, _stream())
@@ -588,8 +605,8 @@ def _outconv_backward(mod, xh, w, patches):
     dw = sk.out("weight", w.shape, dev)
     nb = size_query("erf_wgrad_workspace_bytes", 4 * nc, 16, 1, n * h * wd)
     ws = _ws(nb, dev)
-    call("erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc, ws.data_ptr(), nb,
-         _stream())
+    wgrad_deferred(dev, (ws, dw), "erf_output_conv_wgrad", xh.data_ptr(), patches.data_ptr(), dw.data_ptr(), code, n, h, wd, nc,
+                   ws.data_ptr(), nb, _stream())
     pk = ops.packed_generic(mod, "dgrad", w, code, lambda: _pack_now("erf_output_conv_dgrad", w, code, dev, nc))
     dxh = torch.empty_like(xh)
     call("erf_output_conv_dgrad", patches.data_ptr(), dxh.data_ptr(), pk.data_ptr(), 0, code, n, h, wd, nc, _stream())
@@ -667,8 +684,8 @@ class _PointwiseFn(torch.autograd.Function):
         dw = sk.out("weight", w.shape, dev)
         nb = size_query("erf_wgrad_workspace_bytes", nc, cin, 1, n * h * wd)
         ws = _ws(nb, dev)
-        call("erf_pointwise_wgrad", xh.data_ptr(), g.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, nc, ws.data_ptr(), nb,
-             _stream())
+        wgrad_deferred(dev, (ws, dw), "erf_pointwise_wgrad", xh.data_ptr(), g.data_ptr(), dw.data_ptr(), code, n, h, wd, cin, nc,
+                       ws.data_ptr(), nb, _stream())
         pk = ops.packed_generic(ctx.mod, "dgrad", w, code, lambda: _pack_now("erf_pointwise_dgrad", w, code, dev, cin, nc))
         dxh = torch.empty_like(xh)
         call("erf_pointwise_dgrad", g.data_ptr(), dxh.data_ptr(), pk.data_ptr(), code, n, h, wd, cin, nc, _stream())

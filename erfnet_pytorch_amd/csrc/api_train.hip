@@ -481,6 +481,15 @@ int erf_conv1d_wgrad_partial_many(const erf_wgrad_job* jobs, int count, int dtyp
     return ERF_OK;
 }
 
+// Between begin and end every erf_*_wgrad call of the calling thread leaves its reductions in `descs` (host memory,
+// capacity * erf_wgrad_reduce_desc_bytes()) instead of launching them; end returns how many were recorded.
+int erf_wgrad_reduce_record_begin(void* descs, int capacity) {
+    if (!descs || capacity < 1) return ERF_EINVAL;
+    wgrad_reduce_record_begin((WgradReduceDesc*)descs, capacity);
+    return ERF_OK;
+}
+int erf_wgrad_reduce_record_end(void) { return wgrad_reduce_record_end(); }
+
 int erf_wgrad_reduce_many(const void* table, int count, void* stream) {
     return wgrad_reduce_many_launch(table, count, (hipStream_t)stream);
 }

@@ -54,6 +54,8 @@ int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, in
 // Sum of `nwg` fp32 partial tiles [rows_pad][ncols_pad] (column = tap*cin + ci), scattered into torch weight layout.
 struct WgradReduceDesc { const float* partial; float* dw; int nwg, rows_pad, ncols_pad, cin; PackParams m; };
 void wgrad_reduce_defer(WgradReduceDesc* slot);
+void wgrad_reduce_record_begin(WgradReduceDesc* table, int capacity);
+int wgrad_reduce_record_end();
 int wgrad_reduce_many_launch(const void* table_host, int count, hipStream_t stream);
 int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_pad, int cin, const PackParams& m, float* dw,
                         hipStream_t stream);

@@ -280,12 +280,25 @@ int wgrad_reduce_many_launch(const void* table_host, int count, hipStream_t stre
 static thread_local WgradReduceDesc* t_reduce_slot = nullptr;
 void wgrad_reduce_defer(WgradReduceDesc* slot) { t_reduce_slot = slot; }
 
+// A recorder for entry points that issue several reductions (one per weight phase): while it is open on the calling
+// thread, reductions are appended to its table instead of being launched (the table full: launched as usual).
+static thread_local WgradReduceDesc* t_rec = nullptr;
+static thread_local int t_rec_cap = 0, t_rec_n = 0;
+void wgrad_reduce_record_begin(WgradReduceDesc* table, int capacity) { t_rec = table; t_rec_cap = capacity; t_rec_n = 0; }
+int wgrad_reduce_record_end() { const int n = t_rec_n; t_rec = nullptr; t_rec_cap = t_rec_n = 0; return n; }
+bool wgrad_reduce_recording() { return t_rec != nullptr; }
+
 int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_pad, int cin, const PackParams& m, float* dw,
                         hipStream_t stream) {
     if (t_reduce_slot) {
         WgradReduceDesc& d = *t_reduce_slot;
         d.partial = partial; d.dw = dw; d.nwg = nwg; d.rows_pad = rows_pad; d.ncols_pad = ncols_pad; d.cin = cin; d.m = m;
         t_reduce_slot = nullptr;
+        return ERF_OK;
+    }
+    if (t_rec && t_rec_n < t_rec_cap) {
+        WgradReduceDesc& d = t_rec[t_rec_n++];
+        d.partial = partial; d.dw = dw; d.nwg = nwg; d.rows_pad = rows_pad; d.ncols_pad = ncols_pad; d.cin = cin; d.m = m;
         return ERF_OK;
     }
     const int total = m.cout_virtual * m.ntaps * cin;
@@ -372,10 +385,18 @@ int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, in
     plan(P, (size_t)cot * 16 * ((max_taps * cin + 15) / 16 * 16) * sizeof(float), &nwg, &spw);
     const int epc = dtype == 1 ? 8 : 4;
     if (cin % epc) return ERF_EUNSUPPORTED;
+    // phases get a workspace slice each when the caller left room for that (their reductions can then be put off);
+    // with one shared workspace a phase's partial tiles must be reduced before the next phase overwrites them
+    const size_t per_phase = (size_t)nwg * cot * 16 * ((max_taps * cin + 15) / 16 * 16) * sizeof(float);
+    const bool sliced = geo.nphase > 1 && per_phase * geo.nphase <= workspace_bytes;
+    WgradReduceDesc* const rec = t_rec;
+    if (geo.nphase > 1 && !sliced) t_rec = nullptr;
+    struct Restore { WgradReduceDesc* r; ~Restore() { t_rec = r; } } restore{rec};
     for (int ph = 0; ph < geo.nphase; ++ph) {
         const GConvPhase& g = geo.ph[ph];
+        float* const ws_ph = sliced ? workspace + (per_phase / sizeof(float)) * ph : workspace;
         WgradParams wp{};
-        wp.x = geo.x; wp.dz = dz; wp.partial = workspace;
+        wp.x = geo.x; wp.dz = dz; wp.partial = ws_ph;
         wp.N = geo.N; wp.Hin = geo.Hin; wp.Win = geo.Win; wp.ldx = geo.ldx; wp.xoff = geo.xoff; wp.Hb = geo.Hb; wp.Wb = geo.Wb;
         wp.Hout = geo.Hout; wp.Wout = geo.Wout; wp.lddz = lddz; wp.dzoff = dzoff; wp.Si = geo.Si; wp.So = geo.So;
         wp.oh = g.oh; wp.ow = g.ow; wp.ntaps = g.ntaps;
@@ -388,7 +409,7 @@ int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, in
         int rc = dispatch(wp, dtype, cin, cot, cpw, nwg, stream);
         if (rc) return rc;
         const PackParams& m = maps[ph];
-        rc = wgrad_reduce_launch(workspace, nwg, cot * 16, wp.ncols_pad, cin, m, dw, stream);
+        rc = wgrad_reduce_launch(ws_ph, nwg, cot * 16, wp.ncols_pad, cin, m, dw, stream);
         if (rc) return rc;
     }
     return ERF_OK;

@@ -286,6 +286,13 @@ int erf_wgrad_reduce_many(const void* table, int count, void* stream);
  * proportionally fewer partial tiles.  Every job brings its own workspace of `workspace_bytes`
  * (erf_wgrad_workspace_bytes(C, C, 3, N*H*W)); descs: count * erf_wgrad_reduce_desc_bytes() of host memory.
  * ERF_EUNSUPPORTED (fp32, other channel counts): nothing was launched, use erf_conv1d_wgrad_partial per layer. */
+/* The same deferral for the other weight gradients (down/up-samplers, stem, heads): between
+ * erf_wgrad_reduce_record_begin(descs, capacity) and erf_wgrad_reduce_record_end() -- which returns the number of
+ * descriptors written -- every erf_*_wgrad call of the calling thread leaves its partial-sum reductions pending in `descs`
+ * for a later erf_wgrad_reduce_many; its workspace must stay untouched until then.  A transposed convolution has one
+ * reduction per output phase: they are put off only when the workspace holds 4 x erf_wgrad_workspace_bytes(...). */
+int erf_wgrad_reduce_record_begin(void* descs, int capacity);
+int erf_wgrad_reduce_record_end(void);
 typedef struct erf_wgrad_job { const void* x; const void* dz; float* dw; void* workspace; int axis; int dilation; } erf_wgrad_job;
 int erf_conv1d_wgrad_partial_many(const erf_wgrad_job* jobs, int count, int dtype, int N, int H, int W, int C,
                                   size_t workspace_bytes, void* descs, void* stream);
