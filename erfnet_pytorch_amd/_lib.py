@@ -90,6 +90,7 @@ SIGNATURES = {
     "erf_relu_backward": (I, [P, P, P, I, LL, P]),
     "erf_channel_sum": (I, [P, I, LL, I, P, P, P]),
     "erf_dropout2d_mask": (I, [P, I, F, ULL, P]),
+    "erf_dropout2d_mask_many": (I, [P, I, P, P, P, P]),
     "erf_maxpool2x2_backward": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "erf_ce_workspace_bytes": (c_size_t, []),
     "erf_weighted_ce_fwd": (I, [P, I, P, P, I, I, LL, P, P, P]),

@@ -341,11 +341,37 @@ def conv1d_wgrad_block(jobs):
         conv1d_wgrad(x, dz, tuple(dw.shape), axis, dil, dw, defer=True)
 
 
-def dropout_mask(n, c, p, dev, forced=None):
+def _next_seed():
+    _mask_counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _mask_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def prepare_dropout_masks(mods, n, dev):
+    """The masks of a forward pass for `mods` (the non_bottleneck_1d blocks with p > 0, in forward order) by ONE launch.
+    Each block finds its mask in `_erf_mask_next` and uses it once; seeds advance exactly as if the blocks had drawn their
+    masks one by one, so the values are the same either way."""
+    import numpy as np
+    todo = [m for m in mods if m.__dict__.get("_erf_forced_mask") is None]
+    if not todo or len(todo) > 32:
+        return
+    counts = np.array([n * m.conv3x1_1.out_channels for m in todo], dtype=np.int32)
+    ps = np.array([m.dropout.p for m in todo], dtype=np.float32)
+    seeds = np.array([_next_seed() for _ in todo], dtype=np.uint64)
+    buf = torch.empty(int(counts.sum()), device=dev)
+    call("erf_dropout2d_mask_many", buf.data_ptr(), len(todo), counts.ctypes.data, ps.ctypes.data, seeds.ctypes.data, _stream())
+    off = 0
+    for m, cnt in zip(todo, counts.tolist()):
+        m.__dict__["_erf_mask_next"] = (buf[off:off + cnt].view(n, -1), n)
+        off += cnt
+
+
+def dropout_mask(n, c, p, dev, forced=None, mod=None):
     if forced is not None:
         return forced.to(dev, torch.float32).reshape(n, c).contiguous()
-    _mask_counter[0] += 1
-    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _mask_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    ready = mod.__dict__.pop("_erf_mask_next", None) if mod is not None else None
+    if ready is not None and ready[1] == n and ready[0].shape[1] == c and ready[0].device == dev:
+        return ready[0]
+    seed = _next_seed()
     mask = torch.empty(n * c, device=dev)
     call("erf_dropout2d_mask", mask.data_ptr(), n * c, float(p), seed, _stream())
     return mask.view(n, c)
@@ -402,7 +428,7 @@ class _NB1dFn(torch.autograd.Function):
                                                      mod.bn2, training)
         mask = None
         if training and mod.dropout.p != 0:
-            mask = dropout_mask(xh.shape[0], xh.shape[3], mod.dropout.p, xh.device, mod.__dict__.get("_erf_forced_mask"))
+            mask = dropout_mask(xh.shape[0], xh.shape[3], mod.dropout.p, xh.device, mod.__dict__.get("_erf_forced_mask"), mod)
         out = bn_apply(z4, mean2, s2, t2, residual=xh, mask=mask)
         ctx.save_for_backward(xh, a1, z2, a2, a3, z4, out, mean1, invstd1, mean2, invstd2, w1, w2, w3, w4, g1, g2)
         ctx.mask, ctx.d, ctx.training, ctx.mod = mask, d, training, mod

@@ -176,6 +176,12 @@ int erf_dropout2d_mask(float* mask, int count, float p, unsigned long long seed,
     return dropout_mask_launch(mask, count, p, seed, (hipStream_t)stream);
 }
 
+int erf_dropout2d_mask_many(float* mask, int segments, const int* counts, const float* p, const unsigned long long* seeds,
+                            void* stream) {
+    if (!mask || !counts || !p || !seeds) return ERF_EINVAL;
+    return dropout_mask_many_launch(mask, segments, counts, p, seeds, (hipStream_t)stream);
+}
+
 int erf_maxpool2x2_backward(const void* x, const void* dz, void* dx, int dtype, int N, int Hin, int Win, int Cin, int ldz,
                             int zoff, int accumulate, void* stream) {
     if (!x || !dz || !dx || !dtype_ok(dtype) || N <= 0) return ERF_EINVAL;

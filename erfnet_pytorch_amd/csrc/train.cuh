@@ -27,6 +27,9 @@ int bn_bwd_apply_launch(const void* g, const void* gate, const float* mask, cons
                         long long HW, hipStream_t stream);
 int relu_bwd_launch(const void* g, const void* gate, void* out, int dtype, long long total, hipStream_t stream);
 int dropout_mask_launch(float* mask, int count, float p, unsigned long long seed, hipStream_t stream);
+#define ERF_DROPOUT_MAX 32
+int dropout_mask_many_launch(float* mask, int segments, const int* counts, const float* p, const unsigned long long* seeds,
+                             hipStream_t stream);
 int pool_bwd_launch(const void* x, const void* dz, void* dx, int dtype, int N, int Hin, int Win, int Cin, int ldz, int zoff,
                     int accumulate, hipStream_t stream);
 size_t ce_workspace_bytes();

@@ -396,6 +396,41 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, int count, float p
     mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
 }
 
+// The masks of all Dropout2d layers of a forward pass in one launch: segment s covers mask[begin[s] .. begin[s + 1]) with its
+// own probability and seed; an element's value is what dropout_mask_kernel gives for (seed[s], index within the segment).
+struct DropoutTable { int n; int begin[ERF_DROPOUT_MAX + 1]; float p[ERF_DROPOUT_MAX]; unsigned long long seed[ERF_DROPOUT_MAX]; };
+
+__global__ void dropout_mask_many_kernel(float* __restrict__ mask, const DropoutTable t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.begin[t.n]) return;
+    int s = 0;
+    while (s + 1 < t.n && i >= t.begin[s + 1]) ++s;
+    const float p = t.p[s];
+    unsigned long long x = t.seed[s] + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i - t.begin[s] + 1);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    const float u = (float)(x >> 40) * (1.0f / 16777216.0f);
+    mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+int dropout_mask_many_launch(float* mask, int segments, const int* counts, const float* p, const unsigned long long* seeds,
+                             hipStream_t stream) {
+    if (segments < 1 || segments > ERF_DROPOUT_MAX) return ERF_EINVAL;
+    DropoutTable t{};
+    t.n = segments;
+    long long total = 0;
+    for (int s = 0; s < segments; ++s) {
+        if (counts[s] <= 0 || p[s] < 0.f || p[s] >= 1.f) return ERF_EINVAL;
+        t.begin[s] = (int)total; t.p[s] = p[s]; t.seed[s] = seeds[s];
+        total += counts[s];
+        if (total > 0x7FFFFFFF) return ERF_EINVAL;
+    }
+    t.begin[segments] = (int)total;
+    hipLaunchKernelGGL(dropout_mask_many_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mask, t);
+    return erf_check_launch();
+}
+
 int dropout_mask_launch(float* mask, int count, float p, unsigned long long seed, hipStream_t stream) {
     if (count <= 0 || p < 0.f || p >= 1.f) return ERF_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, mask, count, p, seed);

@@ -59,6 +59,13 @@ def _flush_batch_counters(pending):
         pending.clear()
 
 
+def _prepare_masks(model, images):
+    """All Dropout2d masks of the coming forward pass by one launch (the blocks with p > 0, in forward order)."""
+    if model.training:
+        mods = [m for m in model.modules() if isinstance(m, E.non_bottleneck_1d) and m.dropout.p != 0]
+        ag.prepare_dropout_masks(mods, images.shape[0], images.device)
+
+
 def _refresh_bank(bank, model, images):
     """(Re)build the model's PackedBank for the step's compute dtype and re-pack every factorized-conv weight."""
     from . import ops
@@ -160,6 +167,7 @@ class Trainer:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
         self.zero_grad()                                              # optimizer.zero_grad(), train/main.py:200
         self._refresh_packed(images)
+        _prepare_masks(self.model, images)
         group = self.group if self.world > 1 else None
         if self.fused_head_loss:
             from . import ops
@@ -287,6 +295,7 @@ class ArenaSGD:
     def step(self, images, targets):
         self.zero_grad()
         self._bank = _refresh_bank(getattr(self, "_bank", None), self.model, images)
+        _prepare_masks(self.model, images)
         outputs = self.model(images)
         loss = weighted_cross_entropy(outputs, targets, None, self.group if self.world > 1 else None)
         loss.backward()

@@ -158,6 +158,11 @@ int erf_channel_sum(const void* z, int dtype, long long pixels, int C, float* su
 /* nn.Dropout2d(p) multipliers (train/erfnet.py:55): mask[i] = Bernoulli(1-p)/(1-p), i < count = N*C,
  * a counter-based hash of (seed, i). */
 int erf_dropout2d_mask(float* mask, int count, float p, unsigned long long seed, void* stream);
+/* The masks of up to 32 Dropout2d layers in one launch (every non_bottleneck_1d of a forward pass): segment s of `mask`
+ * has counts[s] elements and holds exactly what erf_dropout2d_mask(., counts[s], p[s], seeds[s]) writes.  counts / p /
+ * seeds are host arrays. */
+int erf_dropout2d_mask_many(float* mask, int segments, const int* counts, const float* p, const unsigned long long* seeds,
+                            void* stream);
 /* MaxPool2d(2, stride 2) backward of the DownsamplerBlock (train/erfnet.py:16,20): routes
  * dz[..., zoff:zoff+Cin] (channel stride ldz) to the first maximum of each window of x;
  * accumulate != 0 adds to dx (after the conv part's data gradient), else overwrites. */

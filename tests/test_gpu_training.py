@@ -746,3 +746,21 @@ def test_fused_head_loss_primitive_vs_torch(nc, dtype, tol):
     assert rel_err(xd.grad.float().cpu(), xr.grad) <= tol
     assert rel_err(wd.grad.cpu(), wr.grad) <= tol
     assert rel_err(bd.grad.cpu(), br.grad) <= tol
+
+
+def test_dropout_masks_of_a_pass_in_one_launch_equal_the_per_layer_masks():
+    """erf_dropout2d_mask_many writes, segment by segment, what erf_dropout2d_mask writes for the same (count, p, seed)."""
+    import numpy as np
+    from erfnet_pytorch_amd._lib import call
+    from erfnet_pytorch_amd import ops
+    counts = np.array([6 * 64, 6 * 64, 6 * 128, 5, 6 * 128], dtype=np.int32)
+    ps = np.array([0.03, 0.03, 0.3, 0.5, 0.3], dtype=np.float32)
+    seeds = np.array([11, 0xFFFFFFFFFFFFFFF1, 12345678901234567, 3, 4], dtype=np.uint64)
+    many = torch.empty(int(counts.sum()), device=DEV)
+    call("erf_dropout2d_mask_many", many.data_ptr(), len(counts), counts.ctypes.data, ps.ctypes.data, seeds.ctypes.data, ops._stream())
+    off = 0
+    for c, p, s in zip(counts.tolist(), ps.tolist(), seeds.tolist()):
+        one = torch.empty(c, device=DEV)
+        call("erf_dropout2d_mask", one.data_ptr(), c, float(p), int(s), ops._stream())
+        assert torch.equal(many[off:off + c], one)
+        off += c
