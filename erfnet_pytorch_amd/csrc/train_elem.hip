@@ -4,6 +4,7 @@
 // one-block finalize in double precision): no float atomics, so results are bit-reproducible.
 #include "common.cuh"
 #include "train.cuh"
+#include "conv1d_tile.cuh"
 
 #define RED_MAX_GROUPS 512
 
@@ -252,6 +253,96 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ z
     }
 }
 
+// The same on 16-byte chunks (8 bf16 / 4 fp32 channels) with 32-bit index arithmetic: the form every launch of the
+// training step takes (C a multiple of the chunk, fewer than 2^31 chunks); the kernel above stays for other shapes.
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_vec_kernel(const i32x4* __restrict__ z, i32x4* __restrict__ y,
+                                                             const float* __restrict__ center, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const i32x4* __restrict__ res,
+                                                             const float* __restrict__ mask, uint32_t total, int C, FastDiv fCv,
+                                                             FastDiv fHW, int relu) {
+    constexpr int E = ChunkOps<T>::N;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t p = fast_div(i, fCv);
+        const int c = (int)(i - p * fCv.div) * E;
+        const i32x4 zr = z[i];
+        i32x4 rr = {0, 0, 0, 0};
+        if (res) rr = res[i];
+        float v[E], a[E], b[E];
+        ChunkOps<T>::unpack(zr, v);
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            *(f32x4*)(a + e) = *(const f32x4*)(scale + c + e);
+            *(f32x4*)(b + e) = *(const f32x4*)(shift + c + e);
+        }
+        if (center) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] -= center[c + e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = v[e] * a[e] + b[e];
+        if (mask) {
+            const float* mk = mask + (size_t)fast_div(p, fHW) * C + c;
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] *= mk[e];
+        }
+        if (res) {
+            float r[E];
+            ChunkOps<T>::unpack(rr, r);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        y[i] = ChunkOps<T>::pack(v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const i32x4* __restrict__ g, const i32x4* __restrict__ gate,
+                                                               const float* __restrict__ mask, const i32x4* __restrict__ z,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ coef, i32x4* __restrict__ dz,
+                                                               i32x4* __restrict__ g_out, uint32_t total, int C, FastDiv fCv,
+                                                               FastDiv fHW) {
+    constexpr int E = ChunkOps<T>::N;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t p = fast_div(i, fCv);
+        const int c = (int)(i - p * fCv.div) * E;
+        const i32x4 gr = g[i], zr = z[i];
+        i32x4 tr = {0, 0, 0, 0};
+        if (gate) tr = gate[i];
+        float v[E], zz[E];
+        ChunkOps<T>::unpack(gr, v);
+        ChunkOps<T>::unpack(zr, zz);
+        if (gate) {
+            float gt[E];
+            ChunkOps<T>::unpack(tr, gt);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = gt[e] > 0.f ? v[e] : 0.f;
+        }
+        if (g_out) g_out[i] = ChunkOps<T>::pack(v);
+        if (mask) {
+            const float* mk = mask + (size_t)fast_div(p, fHW) * C + c;
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] *= mk[e];
+        }
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            o[e] = coef[c + e] * (v[e] - coef[C + c + e] - (zz[e] - mean[c + e]) * invstd[c + e] * coef[2 * C + c + e]);
+        dz[i] = ChunkOps<T>::pack(o);
+    }
+}
+
+template <typename T>
+static bool vec_shape_ok(long long P, int C, long long HW) {
+    constexpr int E = ChunkOps<T>::N;
+    return C % E == 0 && P * (C / E) < 0x7FFFFFFFLL && HW > 0 && HW < 0x7FFFFFFFLL;
+}
+
 static unsigned ew_grid(long long total) {
     long long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
@@ -261,6 +352,18 @@ static unsigned ew_grid(long long total) {
 int bn_apply_launch(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* res, const float* mask,
                     int dtype, long long P, int C, long long HW, int relu, hipStream_t stream) {
     if (C & 3) return ERF_EUNSUPPORTED;
+    if (dtype == 1 ? vec_shape_ok<bf16raw>(P, C, HW) : vec_shape_ok<float>(P, C, HW)) {
+        const int cv = C / (dtype == 1 ? 8 : 4);
+        const long long total = P * cv;
+        const FastDiv fCv = make_fastdiv(cv), fHW = make_fastdiv((int)HW);
+        if (dtype == 1)
+            hipLaunchKernelGGL(affine_act_vec_kernel<bf16raw>, dim3(ew_grid(total)), dim3(256), 0, stream, (const i32x4*)z, (i32x4*)y,
+                               center, scale, shift, (const i32x4*)res, mask, (uint32_t)total, C, fCv, fHW, relu);
+        else
+            hipLaunchKernelGGL(affine_act_vec_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const i32x4*)z, (i32x4*)y,
+                               center, scale, shift, (const i32x4*)res, mask, (uint32_t)total, C, fCv, fHW, relu);
+        return erf_check_launch();
+    }
     const long long total4 = P * (C / 4);
     if (dtype == 1)
         hipLaunchKernelGGL(affine_act_kernel<bf16raw>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const bf16raw*)z,
@@ -346,6 +449,20 @@ int bn_bwd_apply_launch(const void* g, const void* gate, const float* mask, cons
                         const float* invstd, const float* coef, void* dz, void* g_out, int dtype, long long P, int C,
                         long long HW, hipStream_t stream) {
     if (C & 3) return ERF_EUNSUPPORTED;
+    if (dtype == 1 ? vec_shape_ok<bf16raw>(P, C, HW) : vec_shape_ok<float>(P, C, HW)) {
+        const int cv = C / (dtype == 1 ? 8 : 4);
+        const long long total = P * cv;
+        const FastDiv fCv = make_fastdiv(cv), fHW = make_fastdiv((int)HW);
+        if (dtype == 1)
+            hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<bf16raw>, dim3(ew_grid(total)), dim3(256), 0, stream, (const i32x4*)g,
+                               (const i32x4*)gate, mask, (const i32x4*)z, mean, invstd, coef, (i32x4*)dz, (i32x4*)g_out,
+                               (uint32_t)total, C, fCv, fHW);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const i32x4*)g,
+                               (const i32x4*)gate, mask, (const i32x4*)z, mean, invstd, coef, (i32x4*)dz, (i32x4*)g_out,
+                               (uint32_t)total, C, fCv, fHW);
+        return erf_check_launch();
+    }
     const long long total4 = P * (C / 4);
     if (dtype == 1)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16raw>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const bf16raw*)g,
