@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libermi355.so")
 F32, BF16 = 0, 1
 AXIS_H, AXIS_W = 0, 1
 
-_ERRORS = {-1: "invalid argument", -2: "unsupported shape or dtype", -3: "kernel launch failed"}
+_ERRORS = {-1: "invalid argument", -2: "unsupported shape or dtype", -3: "kernel launch failed",
+           -4: "size beyond the fixed limit of the no-allocation entry point (C <= 128)"}
 
 
 class ErfError(RuntimeError):
@@ -136,9 +137,12 @@ SIGNATURES = {
     "erf_pointwise_dgrad_pack": (I, [P, P, I, I, I, P]),
     "erf_pointwise_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
     "erf_pointwise_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
+    "erf_static_scratch_max_channels": (I, []),
+    "erf_bn_stats_finalize_static": (I, [P, I, LL, I, P, P, P, P, F, F, P, P, P, P, P]),
 }
 # entry points whose int return value is data, not a status
-_PLAIN_INT = {"erf_version", "erf_output_conv_patch_channels", "erf_pointwise_grad_channels"}
+_PLAIN_INT = {"erf_version", "erf_output_conv_patch_channels", "erf_pointwise_grad_channels",
+              "erf_static_scratch_max_channels"}
 
 _fn = {}
 for _name, (_res, _args) in SIGNATURES.items():

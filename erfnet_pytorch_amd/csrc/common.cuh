@@ -32,6 +32,7 @@ typedef uint16_t bf16raw;
 #define ERF_EINVAL (-1)
 #define ERF_EUNSUPPORTED (-2)
 #define ERF_ELAUNCH (-3)
+#define ERF_ETOOLARGE (-4)
 
 __device__ __forceinline__ float bf16_to_f32(bf16raw v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16raw f32_to_bf16(float f) {

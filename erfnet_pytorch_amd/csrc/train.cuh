@@ -4,6 +4,8 @@
 #include "pack.cuh"
 #include "gconv.cuh"
 
+// upper bound on the per-workgroup partial rows of every two-stage reduction (workspaces are sized for it)
+#define RED_MAX_GROUPS 512
 size_t bn_workspace_bytes(int C);
 float* bn_workspace_coef(void* workspace, int C);
 int channel_sum_finalize_launch(const float* partials, int groups, int C, float* sums, hipStream_t stream);

@@ -6,7 +6,6 @@
 #include "train.cuh"
 #include "conv1d_tile.cuh"
 
-#define RED_MAX_GROUPS 512
 
 // --------------------------------------------------------------------------------------------
 // Per-channel partial sums over an NHWC tensor.  MODE 0: (sum x, sum x^2).

@@ -11,7 +11,8 @@
  *   - every pointer is a DEVICE pointer unless a comment says "host";
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work on it, never
  *     synchronise, never allocate, never retain pointers beyond the call;
- *   - return value: 0 ok, -1 invalid argument, -2 unsupported shape/dtype, -3 launch failure;
+ *   - return value: 0 ok, -1 invalid argument, -2 unsupported shape/dtype, -3 launch failure,
+ *     -4 size beyond a fixed limit (only the *_static entry point);
  *   - dtype: ERF_F32 (0) or ERF_BF16 (1) = element type of activations and packed weights;
  *     accumulation is always fp32; parameters (weights, scale, shift, bias) are fp32;
  *   - activations are NHWC (channels of a pixel contiguous) except where "NCHW" is stated:
@@ -367,6 +368,19 @@ int erf_maxpool2_avgpool_bwd(const void* x, const float* dfeat, void* dx, int dt
 int erf_linear_fwd(const float* f, const float* w, const float* b, float* y, int N, int C, int K, void* stream);
 int erf_linear_bwd(const float* f, const float* w, const float* dy, float* df, float* dw, float* db, int N, int C, int K,
                    void* stream);
+
+/* ---- the one entry point that allocates nothing and takes no workspace ------------------------------------------
+ * No counterpart in the reference.  It is for callers that cannot allocate device memory: code under HIP-graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.
+ * erf_bn_stats_finalize_static = erf_bn_stats_finalize (same kernels, bit-identical outputs) with the per-workgroup
+ * partial sums kept in a fixed array inside the library's own device image (about 1 MiB per GPU the library runs on,
+ * held until the process ends) instead of a caller workspace.  Limit: C <= erf_static_scratch_max_channels() (128);
+ * larger C returns -4 without launching.  All calls on one GPU share that GPU's array, so calls that overlap on one GPU
+ * (different streams or threads) race; calls on one stream are ordered and safe. */
+int erf_static_scratch_max_channels(void);
+int erf_bn_stats_finalize_static(const void* z, int dtype, long long pixels, int C, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                 float* scale, float* shift, void* stream);
 
 #ifdef __cplusplus
 }
