@@ -83,6 +83,8 @@ SIGNATURES = {
     "erf_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
     "erf_argmax_c": (I, [P, I, P, I, I, I, LL, P]),
     "erf_iou_hist_accumulate": (I, [P, I, P, I, LL, I, P, P]),
+    "erf_iou_planes_workspace_bytes": (c_size_t, [I]),
+    "erf_iou_planes_accumulate": (I, [P, I, P, I, I, I, LL, I, P, P, P]),
     # ---- training
     "erf_bn_workspace_bytes": (c_size_t, [I]),
     "erf_bn_stats_finalize": (I, [P, I, LL, I, P, P, P, P, F, F, P, P, P, P, P, P]),

@@ -170,7 +170,7 @@ def conv1d_dgrad_bias(dy, packed_t, gate, residual, axis, dilation, dbias_out=No
 # and takes the producer's two BatchNorm-backward sums in its epilogue; the producer's backward then finds dz / dgamma /
 # dbeta ready.  Forward: the producer hangs a BnTail on the tensor it returns; the consumer keeps it for its backward.
 # Backward: the consumer leaves a one-slot hand-off that the very next block backward takes (or discards).
-FUSE_BN_BACKWARD = os.environ.get("ERF_FUSE_BN_BACKWARD", "1") != "0"
+FUSE_BN_BACKWARD = True                  # module switch for tests; the environment is never consulted
 FUSED_BN_BACKWARD_CALLS = [0]             # diagnostic counter (tests check that the fused path is the one that runs)
 _HANDOFF = threading.local()             # one slot per backward thread (autograd runs one thread per device)
 
@@ -385,8 +385,21 @@ class _Sink:
     are enqueued -- the hook gradient-bucket all-reduces hang on.  An owner of a sink calls flush_bias_sums()
     after backward(): the convolution-bias gradients are complete only then."""
 
-    def __init__(self, mod):
+    def __init__(self, mod, claim=True):
+        """claim=False: only look the views up (a block writing a NEIGHBOUR's BatchNorm gradients on its behalf)."""
         self.views = mod.__dict__.get("_erf_grad_sink") if mod is not None else None
+        if self.views is not None and claim:
+            # The kernels OVERWRITE the arena views (torch would accumulate into .grad).  The arena's owner counts its
+            # zero_grad() calls in `_erf_grad_sink_epoch`; a second backward pass through the same block before the next
+            # zero_grad() would silently replace the first one's gradients, so it is refused.
+            epoch = mod.__dict__.get("_erf_grad_sink_epoch")
+            if epoch is not None:
+                if mod.__dict__.get("_erf_grad_sink_written") == epoch[0]:
+                    raise RuntimeError(
+                        f"{type(mod).__name__}: second backward pass into a trainer-owned gradient arena before zero_grad(); "
+                        "gradient accumulation (several backward calls per step, auxiliary losses, a block applied twice in one "
+                        "graph) is not supported on a model owned by Trainer / ArenaSGD -- train it through .step() only")
+                mod.__dict__["_erf_grad_sink_written"] = epoch[0]
         # the owner of the arena clears it before every backward pass: analytic zeros need no fill of their own
         self.zeroed = self.views is not None and bool(mod.__dict__.get("_erf_grad_sink_zeroed"))
         self.after = mod.__dict__.get("_erf_after_backward") if mod is not None else None
@@ -468,7 +481,7 @@ class _NB1dFn(torch.autograd.Function):
                                      o("conv3x1_1.bias", (c,)), defer=True)
         t, fused = ctx.tail, None
         if t is not None:                     # this block's input is the ReLU output of a BatchNorm: run that layer's backward here
-            psk = _Sink(t.mod)
+            psk = _Sink(t.mod, claim=False)
             fused = conv1d_dgrad_bn_backward(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), xh, g_res, AXIS_H, 1, t.z,
                                              t.mean, t.invstd, _f32(t.gamma), t.mask, t.training,
                                              psk.out(t.prefix + ".weight", (c,), dev), psk.out(t.prefix + ".bias", (c,), dev))

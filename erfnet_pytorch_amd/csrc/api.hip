@@ -355,4 +355,12 @@ int erf_iou_hist_accumulate(const void* pred, int pred_bytes, const void* label,
     return iou_hist_launch(pred, pred_bytes, label, label_bytes, count, nc, hist, (hipStream_t)stream);
 }
 
+size_t erf_iou_planes_workspace_bytes(int nc) { return iou_planes_workspace_bytes(nc); }
+
+int erf_iou_planes_accumulate(const void* x, int x_kind, const void* y, int y_kind, int N, int nc, long long HW, int ignore_index,
+                              double* sums, void* workspace, void* stream) {
+    if (!x || !y || !sums || !workspace || N <= 0 || HW <= 0) return ERF_EINVAL;
+    return iou_planes_launch(x, x_kind, y, y_kind, N, nc, HW, ignore_index, sums, (double*)workspace, (hipStream_t)stream);
+}
+
 }  // extern "C"

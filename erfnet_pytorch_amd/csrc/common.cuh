@@ -112,6 +112,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Developer knobs (tile-count sweeps, kernel bypasses, phase ablation) are read from the environment only in builds
+// made with -DERF_DEBUG.  The product library never looks at the environment: every call computes what its arguments say.
+#ifdef ERF_DEBUG
+#include <stdlib.h>
+static inline int erf_debug_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int erf_debug_env(const char*, int dflt) { return dflt; }
+#endif
+
 static inline int erf_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ERF_OK : ERF_ELAUNCH;

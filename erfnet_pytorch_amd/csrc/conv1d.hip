@@ -238,8 +238,8 @@ static int launch_cfg(Conv1dParams p, int N, int H, int W, int axis, hipStream_t
     const int wave_limit = 8 / (NT / 64) > 0 ? 8 / (NT / 64) : 1;       // 2 waves per SIMD
     if (wg_per_cu > wave_limit) wg_per_cu = wave_limit;
     if (wg_per_cu < 1) wg_per_cu = 1;
-    if (const char* e = getenv("ERF_CONV1D_DBG")) p.dbg = atoi(e);
-    if (const char* e = getenv("ERF_CONV1D_WGPCU")) wg_per_cu = atoi(e);
+    p.dbg = erf_debug_env("ERF_CONV1D_DBG", 0);
+    wg_per_cu = erf_debug_env("ERF_CONV1D_WGPCU", wg_per_cu);
     int grid = 256 * wg_per_cu;
     if (grid > p.ntiles) grid = p.ntiles;
     auto kern = conv1d_kernel<T, C, WM, WN, M, MAXK>;

@@ -487,8 +487,7 @@ static int launch_buf(BufParams p, int N, int H, int W, int axis, int* groups, h
         if (p.bmask && axis != 0) return ERF_EUNSUPPORTED;       // the mask is per image: tiles must not mix images
         // fp32 at 128 channels does not fit the register file with the BatchNorm-backward epilogue (216 bytes of scratch
         // per lane); that instance is not built -- the caller runs the BatchNorm backward as its own pass.
-        if constexpr (sizeof(T) == 4 && C == 128) return ERF_EUNSUPPORTED;
-        else ERF_LAUNCH_BUF(true, 2)
+        ERF_LAUNCH_BUF(true, 2)
     } else if (p.stats) { if (post) ERF_LAUNCH_BUF(true, 1) else ERF_LAUNCH_BUF(false, 1) }
     else { if (post) ERF_LAUNCH_BUF(true, 0) else ERF_LAUNCH_BUF(false, 0) }
 #undef ERF_LAUNCH_BUF
@@ -501,7 +500,7 @@ int conv1d_buf_max_groups() { return 512; }
 int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, const void* residual,
                       const void* gate, double* stats, int* groups, int dtype, int N, int H, int W, int C, int axis, int dilation,
                       int relu, hipStream_t stream, const Conv1dBnTail* tail) {
-    static const int off = getenv("ERF_CONV1D_BUF_OFF") ? atoi(getenv("ERF_CONV1D_BUF_OFF")) : 0;
+    static const int off = erf_debug_env("ERF_CONV1D_BUF_OFF", 0);
     if (off) return ERF_EUNSUPPORTED;
     BufParams p{};
     p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual; p.gate = gate; p.stats = stats;

@@ -476,7 +476,7 @@ int conv1d_pair_launch(const void* x, void* y, const void* packedA, const void* 
     p.x = (const T*)x; p.y = (T*)y; p.wA = packedA; p.wB = packedB;
     p.scaleA = scaleA; p.shiftA = shiftA; p.scaleB = scaleB; p.shiftB = shiftB; p.res = (const T*)residual;
     p.d = dilation; p.relu = relu; p.N = N; p.H = H; p.W = W;
-    static const int dbg = getenv("ERF_PAIR_DBG") ? atoi(getenv("ERF_PAIR_DBG")) : 0;
+    static const int dbg = erf_debug_env("ERF_PAIR_DBG", 0);
     p.dbg = dbg;
     // Sparse lattices (few points per residue class) waste most of a tile: leave those to two single launches.
     if (C == 128) {

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const T* __restrict__ x, c
         const unsigned n = fast_div(rest, fH);
         const int i = (int)(rest - n * fH.div);
         const long long o = ((long long)n * Hout + 2 * i + (q >> 1)) * Wout + 2 * j + (q & 1);
-        const int tg = pv ? (int)target[o] : 0;
+        const long long tg64 = pv ? target[o] : 0;
+        const int tg = (tg64 >= -100 && tg64 < 0x7fffffff) ? (int)tg64 : -1;
         float m = -INFINITY;
 #pragma unroll
         for (int k = 0; k < CT * 4; ++k)
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(256) void head_ce_kernel(const T* __restrict__ x, c
                 s += __expf(val[k] - m);
                 zt = k == tg ? val[k] : zt;
             }
-        const bool tv = pv && tg >= 0 && tg < nc;                    // labels outside [0, nc) carry no weight
-        const float wt = tv ? (weight ? weight[tg] : 1.f) : 0.f;
+        // a label outside [0, nc) other than torch's ignore_index (-100) makes torch raise; here it poisons the sums with NaN
+        const bool tv = pv && tg >= 0 && tg < nc;
+        const float wt = tv ? (weight ? weight[tg] : 1.f) : ((!pv || tg == -100) ? 0.f : __builtin_nanf(""));
         if (!BWD) {
             num += wt * (m + __logf(s) - zt);
             den += wt;

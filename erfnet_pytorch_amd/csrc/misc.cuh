@@ -15,5 +15,8 @@ int transpose_launch(const void* src, int sdt, void* dst, int ddt, int N, long l
 int argmax_launch(const void* z, int dtype, void* lab, int label_bytes, int N, int C, long long HW, hipStream_t stream);
 int iou_hist_launch(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count, int nc,
                     long long* hist, hipStream_t stream);
+size_t iou_planes_workspace_bytes(int nc);
+int iou_planes_launch(const void* x, int x_kind, const void* y, int y_kind, int N, int nc, long long HW, int ignore, double* sums,
+                      double* workspace, hipStream_t stream);
 int outconv_launch(const void* x, const void* packed, const float* bias, void* logits, int logits_f32, void* labels,
                    int label_bytes, int dtype, int N, int Hin, int Win, int nc, hipStream_t stream);

@@ -266,3 +266,75 @@ int iou_hist_launch(const void* pred, int pred_bytes, const void* label, int lab
 #undef IH
     return erf_check_launch();
 }
+
+// --------------------------------------------------------------------------------------------
+// iouEval.addBatch for inputs given as N x nClasses x H x W planes (one-hot or soft scores) instead of label maps:
+//     tp_c += sum x_c * y_c,  fp_c += sum x_c * (1 - y_c - y_ignore),  fn_c += sum (1 - x_c) * y_c      (c < classes)
+// Either side may still be a label map (kind 1: int64, kind 2: uint8), which is its one-hot expansion on the fly.
+// blockIdx.y = class, blockIdx.x = pixel slice; fp64 sums per thread, one partial row per block, summed in block order.
+#define IOU_PLANE_ROWS 256
+template <int XK, int YK>
+__global__ __launch_bounds__(256) void iou_planes_kernel(const void* __restrict__ xv, const void* __restrict__ yv, int N, int nc,
+                                                         long long HW, int ignore, double* __restrict__ partials) {
+    const int c = blockIdx.y, classes = gridDim.y;
+    const long long total = (long long)N * HW;
+    double tp = 0, fp = 0, fn = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW, hw = i - n * HW;
+        float x, y, ig = 0.f;
+        if (XK == 0) x = ((const float*)xv)[(n * nc + c) * HW + hw];
+        else if (XK == 1) x = ((const long long*)xv)[i] == c ? 1.f : 0.f;
+        else x = ((const unsigned char*)xv)[i] == c ? 1.f : 0.f;
+        if (YK == 0) {
+            y = ((const float*)yv)[(n * nc + c) * HW + hw];
+            if (ignore >= 0) ig = ((const float*)yv)[(n * nc + ignore) * HW + hw];
+        } else {
+            const long long t = YK == 1 ? ((const long long*)yv)[i] : (long long)((const unsigned char*)yv)[i];
+            y = t == c ? 1.f : 0.f;
+            ig = (ignore >= 0 && t == ignore) ? 1.f : 0.f;
+        }
+        tp += (double)(x * y);
+        fp += (double)(x * (1.f - y - ig));
+        fn += (double)((1.f - x) * y);
+    }
+    __shared__ double red[3][256];
+    red[0][threadIdx.x] = tp; red[1][threadIdx.x] = fp; red[2][threadIdx.x] = fn;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partials[((long long)blockIdx.x * 3 + threadIdx.x) * classes + c] = red[threadIdx.x][0];
+}
+
+__global__ void iou_planes_finalize_kernel(const double* __restrict__ partials, int rows, int classes, double* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;             // (kind, class)
+    if (i >= 3 * classes) return;
+    double a = 0;
+    for (int r = 0; r < rows; ++r) a += partials[(long long)r * 3 * classes + i];
+    sums[i] += a;
+}
+
+size_t iou_planes_workspace_bytes(int nc) { return (size_t)IOU_PLANE_ROWS * 3 * (nc > 0 ? nc : 1) * sizeof(double); }
+
+int iou_planes_launch(const void* x, int x_kind, const void* y, int y_kind, int N, int nc, long long HW, int ignore, double* sums,
+                      double* workspace, hipStream_t stream) {
+    if (nc <= 0 || nc > 64 || ignore >= nc || x_kind < 0 || x_kind > 2 || y_kind < 0 || y_kind > 2) return ERF_EINVAL;
+    const int classes = ignore >= 0 ? ignore : nc;                    // the reference keeps channels [0, ignoreIndex)
+    if (classes <= 0) return ERF_EINVAL;
+    const long long total = (long long)N * HW;
+    long long rows = (total + 256 * 16 - 1) / (256 * 16);
+    if (rows > IOU_PLANE_ROWS) rows = IOU_PLANE_ROWS;
+    if (rows < 1) rows = 1;
+    const dim3 grid((unsigned)rows, (unsigned)classes);
+#define IP(XK, YK) hipLaunchKernelGGL((iou_planes_kernel<XK, YK>), grid, dim3(256), 0, stream, x, y, N, nc, HW, ignore, workspace)
+    switch (x_kind * 3 + y_kind) {
+        case 0: IP(0, 0); break; case 1: IP(0, 1); break; case 2: IP(0, 2); break;
+        case 3: IP(1, 0); break; case 4: IP(1, 1); break; case 5: IP(1, 2); break;
+        case 6: IP(2, 0); break; case 7: IP(2, 1); break; default: IP(2, 2); break;
+    }
+#undef IP
+    hipLaunchKernelGGL(iou_planes_finalize_kernel, dim3((3 * classes + 63) / 64), dim3(64), 0, stream, workspace, (int)rows, classes, sums);
+    return erf_check_launch();
+}

@@ -628,8 +628,12 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ z, const 
         const long long n = idx / HW, hw = idx % HW;
         const T* p = z + n * C * HW + hw;
         const long long t = target[idx];
-        const bool valid = t >= 0 && t < C;
-        const float w = valid ? (weight ? weight[t] : 1.f) : 0.f;
+        // torch's CrossEntropyLoss raises on a target outside [0, C) other than its ignore_index (-100); a kernel cannot raise
+        // without a host round trip, so such a pixel gets a NaN weight: the loss and the gradients turn NaN at once instead of
+        // training on silently with a different denominator
+        const bool inrange = t >= 0 && t < C;
+        const bool valid = inrange || t != -100;
+        const float w = inrange ? (weight ? weight[t] : 1.f) : (t == -100 ? 0.f : __builtin_nanf(""));
         if constexpr (NC > 0) {
             float v[NC];
 #pragma unroll
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const T* __restrict__ z, const 
         for (int c = 0; c < C; ++c) se += __expf(Elem<T>::ld(p + c * HW) - m);
         if (!BWD) {
             if (valid) {
-                const float zt = Elem<T>::ld(p + t * HW);
+                const float zt = inrange ? Elem<T>::ld(p + t * HW) : 0.f;
                 acc_l += w * (m + __logf(se) - zt);
                 acc_w += w;
             }

@@ -313,8 +313,8 @@ int wgrad_reduce_launch(const float* partial, int nwg, int rows_pad, int ncols_p
 // (few KB of partial sums per workgroup) take up to 2048 workgroups for occupancy; large tiles stay at 512 so that the
 // partial sums the reduction reads back stay within ~24 MB.
 static void plan(long long P, size_t tile_bytes, int* nwg, int* spw) {
-    static const int forced = getenv("ERF_WGRAD_WGS") ? atoi(getenv("ERF_WGRAD_WGS")) : 0;
-    static const int smin = getenv("ERF_WGRAD_SMIN") ? atoi(getenv("ERF_WGRAD_SMIN")) : 8;
+    static const int forced = erf_debug_env("ERF_WGRAD_WGS", 0);
+    static const int smin = erf_debug_env("ERF_WGRAD_SMIN", 8);
     long long target = forced;
     if (target <= 0) {
         target = (long long)((24u << 20) / (tile_bytes ? tile_bytes : 1));

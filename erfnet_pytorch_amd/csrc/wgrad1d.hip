@@ -309,8 +309,8 @@ static int launch_w1d(const W1dJob* jobs, int count, int N, int H, int W, const 
     for (int i = count; i < ERF_W1D_MAX; ++i) tab.p[i] = tab.p[0];
     // one layer alone: 128 workgroups per unit of occupancy (more only adds partial tiles); several layers share one
     // workgroup per CU (measured at 128 / 256 / 512 / 768 / 1024 in all: 256 is the fastest for every channel count)
-    static const int want = getenv("ERF_WGRAD1D_WGS") ? atoi(getenv("ERF_WGRAD1D_WGS")) : 128;
-    static const int want_many = getenv("ERF_WGRAD1D_WGS_MANY") ? atoi(getenv("ERF_WGRAD1D_WGS_MANY")) : 256;
+    static const int want = erf_debug_env("ERF_WGRAD1D_WGS", 128);
+    static const int want_many = erf_debug_env("ERF_WGRAD1D_WGS_MANY", 256);
     const size_t tile_bytes = (size_t)C * 3 * C * sizeof(float);
     long long grid = count == 1 ? (long long)want * OCC : (long long)want_many / count;
     if (grid > ntiles_min) grid = ntiles_min;
@@ -334,7 +334,7 @@ static int launch_w1d(const W1dJob* jobs, int count, int N, int H, int W, const 
 int wgrad1d_many_launch(const W1dJob* jobs, int count, int dtype, int N, int H, int W, int C, const PackParams* maps,
                         size_t workspace_bytes, WgradReduceDesc* descs, hipStream_t stream) {
     if (dtype != 1) return ERF_EUNSUPPORTED;
-    static const int off = getenv("ERF_WGRAD1D_OFF") ? atoi(getenv("ERF_WGRAD1D_OFF")) : 0;
+    static const int off = erf_debug_env("ERF_WGRAD1D_OFF", 0);
     if (off) return ERF_EUNSUPPORTED;
     if (C == 128) return launch_w1d<128, 8, 1, 3, 128, 6, 4>(jobs, count, N, H, W, maps, workspace_bytes, descs, stream);
     if (C == 64) return launch_w1d<64, 4, 1, 3, 128, 5, 4>(jobs, count, N, H, W, maps, workspace_bytes, descs, stream);

@@ -10,6 +10,10 @@ histogram with LDS atomics (erf_iou_hist_accumulate), kept as int64 on the devic
     fp_c = sum_{g != ignore} H[g][c] - tp_c           (prediction == c, label != c, label not ignored)
 
 All counts are exact integers (the reference's float32 sums are exact only up to 2^24 per call).
+
+Inputs that already have nClasses planes (one-hot or soft scores; train/iouEval.py:37-38,45-46 take them as they are)
+go through erf_iou_planes_accumulate instead: tp/fp/fn sums of the plane products in float64, kept beside the histogram
+and added to the counts above on access.
 """
 from __future__ import annotations
 
@@ -32,18 +36,61 @@ class iouEval:
     def reset(self):
         self._hist = None
         self._host = torch.zeros(self.nClasses * self.nClasses + 1, dtype=torch.int64)
+        self._planes = None                        # float64 [3, classes] on the device: tp / fp / fn of plane-form batches
+        self._planes_host = None
 
     # -- counting ---------------------------------------------------------------------------
     def addBatch(self, x, y):  # x = predictions, y = targets; both [N,1,H,W] (or [N,H,W]) label maps
-        if x.dim() == 4 and x.size(1) != 1 or y.dim() == 4 and y.size(1) != 1:
-            raise NotImplementedError("iouEval.addBatch takes label maps (size(1) == 1); one-hot input is not supported")
         ops.require_gpu(x if x.is_cuda else y, "iouEval.addBatch")
         dev = x.device if x.is_cuda else y.device
         x, y = x.to(dev), y.to(dev)           # the reference moves both to the GPU when either is there (:27-29)
+        if x.dim() == 4 and x.size(1) != 1 or y.dim() == 4 and y.size(1) != 1:
+            return self._add_planes(x, y, dev)
         if self._hist is None or self._hist.device != dev:
             self._flush()
             self._hist = torch.zeros(self.nClasses * self.nClasses + 1, dtype=torch.int64, device=dev)
         ops.iou_hist_accumulate(x, y, self.nClasses, self._hist)
+
+    def _add_planes(self, x, y, dev):
+        """At least one input comes as N x nClasses x H x W planes (train/iouEval.py:32-46 `else` branches)."""
+        from ._lib import call, size_query
+
+        def prep(t, who):
+            if t.dim() == 4 and t.size(1) != 1:
+                if t.size(1) != self.nClasses:
+                    raise ValueError(f"iouEval.addBatch: {who} has {t.size(1)} planes, expected 1 or nClasses = {self.nClasses}")
+                return t.float().contiguous(), 0
+            if t.dtype not in (torch.uint8, torch.int64):
+                t = t.long()
+            return t.contiguous(), (1 if t.dtype == torch.int64 else 2)
+        xs, xk = prep(x, "x")
+        ys, yk = prep(y, "y")
+        n, hw = x.size(0), x.shape[-1] * x.shape[-2]
+        if y.size(0) != n or y.shape[-1] * y.shape[-2] != hw:
+            raise ValueError("prediction and label maps differ in size")
+        classes = self.nClasses if self.ignoreIndex == -1 else self.ignoreIndex
+        if self.ignoreIndex not in (-1, self.nClasses - 1):
+            # the reference keeps planes [0, ignoreIndex) but nClasses - 1 accumulators (:16,50-51): it fails on this too
+            raise ValueError("iouEval: plane-form inputs need ignoreIndex == nClasses - 1 or no ignore class")
+        if self._planes is None or self._planes.device != dev:
+            self._flush_planes()
+            self._planes = torch.zeros(3, classes, dtype=torch.float64, device=dev)
+        ws = torch.empty(size_query("erf_iou_planes_workspace_bytes", self.nClasses), dtype=torch.uint8, device=dev)
+        call("erf_iou_planes_accumulate", xs.data_ptr(), xk, ys.data_ptr(), yk, n, self.nClasses, hw, self.ignoreIndex,
+             self._planes.data_ptr(), ws.data_ptr(), ops._stream())
+
+    def _flush_planes(self):
+        if self._planes is not None:
+            h = self._planes.cpu()
+            self._planes_host = h if self._planes_host is None else self._planes_host + h
+            self._planes = None
+
+    def _plane_sums(self):
+        tot = self._planes_host
+        if self._planes is not None:
+            h = self._planes.cpu()
+            tot = h if tot is None else tot + h
+        return tot
 
     def _flush(self):
         if self._hist is not None:
@@ -68,7 +115,11 @@ class iouEval:
         col = h.sum(dim=0)[:classes] - diag
         if self.ignoreIndex != -1:
             col = col - h[self.ignoreIndex, :classes]
-        return diag.clone(), col, fn
+        tp = diag.clone()
+        extra = self._plane_sums()
+        if extra is not None:
+            tp, col, fn = tp + extra[0], col + extra[1], fn + extra[2]
+        return tp, col, fn
 
     @property
     def tp(self):

@@ -79,10 +79,12 @@ def _refresh_bank(bank, model, images):
 
 class Trainer:
     def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
-                 group=None, world_size=1, overlap=True, only_encode=False, fused_head_loss=True):
+                 group=None, world_size=1, overlap=True, only_encode=False, fused_head_loss=True, force_collectives=False):
         """`only_encode`: the first stage of the reference's recipe (train/main.py:495 `train(args, model, True)`,
         :203 `model(inputs, only_encode=enc)`): logits from Encoder.output_conv at 1/8 resolution against targets of
-        that size; the decoder's parameters take no part and are left untouched."""
+        that size; the decoder's parameters take no part and are left untouched.
+        `force_collectives`: issue the loss and gradient-bucket all-reduces even when world_size is 1 (a one-rank process
+        group exercises the whole collective path -- hooks, side-stream ordering, waits -- on a single GPU)."""
         self.model = model
         self.only_encode = only_encode
         # Decoder.output_conv + loss in one pass each way (the logits stay in registers); step() then returns
@@ -91,13 +93,15 @@ class Trainer:
         self.group, self.world = group, world_size
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_count = 0
-        self.overlap = overlap and world_size > 1
+        self.collective = world_size > 1 or (force_collectives and group is not None)
+        self.overlap = overlap and self.collective
         dev = next(model.parameters()).device
         self.dev = dev
         self.weight = None if class_weights is None else torch.tensor(class_weights, dtype=torch.float32, device=dev)
 
         named = list(model.named_parameters())
         total = sum(p.numel() for _, p in named)
+        self._epoch = [0]                               # zero_grad() calls so far (see autograd._Sink)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
         self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -125,6 +129,7 @@ class Trainer:
                 views[k] = self.gflat[o:o + n].view_as(prm)
             mod.__dict__["_erf_grad_sink"] = views
             mod.__dict__["_erf_grad_sink_zeroed"] = True    # step() clears the arena before every backward pass
+            mod.__dict__["_erf_grad_sink_epoch"] = self._epoch
 
         self._bank = None                               # packed factorized-conv weights, refreshed once per step
         self._counted = _take_over_batch_counters(model)
@@ -145,7 +150,7 @@ class Trainer:
         self._pending.append(dist.all_reduce(self.gflat[lo:hi], group=self.group, async_op=True))
 
     def _reduce_gradients(self):
-        if self.world == 1:
+        if not self.collective:
             return
         if not self.overlap:
             for i in range(len(self.buckets)):
@@ -159,6 +164,7 @@ class Trainer:
         self.lr = poly_lr(base_lr, epoch, num_epochs)
 
     def zero_grad(self):
+        self._epoch[0] += 1
         self.gflat.zero_()
 
     def step(self, images, targets):
@@ -168,7 +174,7 @@ class Trainer:
         self.zero_grad()                                              # optimizer.zero_grad(), train/main.py:200
         self._refresh_packed(images)
         _prepare_masks(self.model, images)
-        group = self.group if self.world > 1 else None
+        group = self.group if self.collective else None
         if self.fused_head_loss:
             from . import ops
             ops.require_gpu(images, "Trainer")
@@ -260,6 +266,7 @@ class ArenaSGD:
         self.model, self.lr, self.momentum, self.wd = model, lr, momentum, weight_decay
         self.group, self.world = group, world_size
         self.step_count = 0
+        self._epoch = [0]
         named = list(model.named_parameters())
         dev = named[0][1].device
         total = sum(p.numel() for _, p in named)
@@ -284,10 +291,12 @@ class ArenaSGD:
                 sunk.add(f"{mname}.{k}")
             mod.__dict__["_erf_grad_sink"] = views
             mod.__dict__["_erf_grad_sink_zeroed"] = True    # step() clears the arena before every backward pass
+            mod.__dict__["_erf_grad_sink_epoch"] = self._epoch
         self._views = [(p, self.gflat[o:o + n].view_as(p)) for (name, p), (o, n) in
                        ((np_, self.offsets[np_[0]]) for np_ in named) if name not in sunk]
 
     def zero_grad(self):
+        self._epoch[0] += 1
         self.gflat.zero_()
         for p, v in self._views:
             p.grad = v                                  # autograd accumulates in place into the arena

@@ -125,6 +125,16 @@ int erf_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, i
 int erf_argmax_c(const void* logits, int dtype, void* labels, int label_bytes, int N, int C, long long HW, void* stream);
 int erf_iou_hist_accumulate(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count,
                             int nc, long long* hist, void* stream);
+/* iouEval.addBatch when an input already has nClasses planes (train/iouEval.py:32-46 `else: x_onehot = x.float()`): the
+ * reference then multiplies the planes as they are (one-hot or soft scores), :60-65.  sums [3][classes] fp64 (tp, fp, fn;
+ * classes = ignore_index when ignore_index >= 0, else nc) is ADDED to:
+ *   tp_c += sum x_c*y_c, fp_c += sum x_c*(1 - y_c - y_ignore), fn_c += sum (1 - x_c)*y_c.
+ * x_kind / y_kind: 0 = fp32 planes NCHW [N,nc,HW], 1 = int64 label map [N,HW], 2 = uint8 label map (expanded on the fly).
+ * Products are formed in fp32 like the reference's, sums in fp64 in a fixed order (the reference sums in fp32: equal for
+ * one-hot inputs, which give integers). workspace: erf_iou_planes_workspace_bytes(nc). */
+size_t erf_iou_planes_workspace_bytes(int nc);
+int erf_iou_planes_accumulate(const void* x, int x_kind, const void* y, int y_kind, int N, int nc, long long HW, int ignore_index,
+                              double* sums, void* workspace, void* stream);
 
 /* =========================== training step =============================================== */
 
@@ -171,8 +181,9 @@ int erf_maxpool2x2_backward(const void* x, const void* dz, void* dx, int dtype, 
                             int zoff, int accumulate, void* stream);
 
 /* ---- loss: torch.nn.CrossEntropyLoss(weight), train/main.py:121,202 (= CrossEntropyLoss2d :72-80)
- * fwd: out3 = { sum_p w[t_p]*nll_p, sum_p w[t_p], their quotient }; targets outside [0,C) count as
- *   ignored.  The two sums are returned separately so that data-parallel ranks can divide by the
+ * fwd: out3 = { sum_p w[t_p]*nll_p, sum_p w[t_p], their quotient }; a target of -100 (torch's ignore_index) carries no
+ *   weight; any other target outside [0,C) -- on which torch raises -- gives NaN sums and NaN gradients (loud, and without a
+ *   host round trip).  The two sums are returned separately so that data-parallel ranks can divide by the
  *   GLOBAL denominator, as DataParallel's loss over the gathered batch does.
  * bwd: dlogits = coef[0] * w[t] * (softmax - onehot), coef a DEVICE scalar (grad_output / denominator).
  * logits / dlogits NCHW of `dtype`; target int64 [N,H,W]; weight fp32 [C] or NULL. */

@@ -238,6 +238,26 @@ def iou_counts(pred: torch.Tensor, label: torch.Tensor, n_classes: int, ignore_i
     return tp, fp, fn
 
 
+def iou_plane_sums(x: torch.Tensor, y: torch.Tensor, n_classes: int, ignore_index: int = 19):
+    """tp/fp/fn per class (float64) when x and/or y come as N x nClasses x H x W planes (train/iouEval.py:32-65): label maps
+    are expanded to one-hot planes, planes are taken as they are; products in float32 as in the reference, sums in float64."""
+    ign = ignore_index if n_classes > ignore_index else -1
+
+    def planes(t):
+        if t.size(1) == 1:
+            return torch.zeros(t.size(0), n_classes, t.size(2), t.size(3)).scatter_(1, t.long(), 1)
+        return t.float()
+    xo, yo = planes(x), planes(y)
+    ignores = 0
+    if ign != -1:
+        ignores = yo[:, ign].unsqueeze(1)
+        xo, yo = xo[:, :ign], yo[:, :ign]
+    tp = (xo * yo).double().sum(dim=(0, 2, 3))
+    fp = (xo * (1 - yo - ignores)).double().sum(dim=(0, 2, 3))
+    fn = ((1 - xo) * yo).double().sum(dim=(0, 2, 3))
+    return tp, fp, fn
+
+
 def iou_from_counts(tp, fp, fn):
     iou = tp / (tp + fp + fn + 1e-15)        # train/iouEval.py:71-75
     return iou.mean(), iou

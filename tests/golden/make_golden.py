@@ -215,6 +215,20 @@ def g4_iou():
         mean, per = ev.getIoU()
         out[f"nc{nc}_iou_mean"] = np.array(mean.item())
         out[f"nc{nc}_iou"] = per.numpy().copy()
+    # inputs that already have nClasses planes (train/iouEval.py:37-38,45-46): one-hot predictions against a label map,
+    # a label map against one-hot targets, and soft scores (softmax of seeded noise) against one-hot targets
+    for nc in (20, 4):
+        pred = S.synthetic_labels(2, 24, 40, nc, seed=471, ignore_frac=0.0)
+        lab = S.synthetic_labels(2, 24, 40, nc, seed=472, ignore_frac=0.07 if nc == 20 else 0.0)
+        onehot = lambda t: torch.zeros(t.size(0), nc, t.size(2), t.size(3)).scatter_(1, t, 1)
+        soft = torch.softmax(3.0 * upstream((2, nc, 24, 40), 473), dim=1)
+        for tag, (x, y) in {"onehot_x": (onehot(pred), lab), "onehot_y": (pred, onehot(lab)),
+                            "soft_x": (soft, onehot(lab))}.items():
+            ev = ref_iou.iouEval(nc)
+            ev.addBatch(x, y)
+            ev.addBatch(x, y)                     # accumulation over two calls
+            for k in ("tp", "fp", "fn"):
+                out[f"planes_nc{nc}_{tag}_{k}"] = getattr(ev, k).numpy().copy()
     np.savez_compressed(os.path.join(HERE, "g4_iou.npz"), **out)
 
 

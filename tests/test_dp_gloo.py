@@ -21,12 +21,6 @@ from oracle import erfnet_oracle as O
 H, W, NC = 32, 64, 20
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 # Everything runs in float64: end-to-end fp32 gradients of this deep training-mode graph move by ~1e-2
 # with the summation order alone (thread count), which would mask the exact identity checked here.
 def _state():
@@ -53,11 +47,10 @@ def _leaf(sd):
     return {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v) for k, v in sd.items()}
 
 
-def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _worker(rank, world, store_file, q):
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file store: no TCP port has to be guessed free in advance, so there is no bind race to retry
+    dist.init_process_group("gloo", init_method=f"file://{store_file}", rank=rank, world_size=world)
     try:
         sd = _state()
         w = torch.tensor(O.CITYSCAPES_WEIGHTS, dtype=torch.float64)
@@ -88,14 +81,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _run_world(world):
-    """Spawn `world` gloo ranks on 127.0.0.1 and return rank 0's result (None if the rendezvous did not come up:
-    the free port found a moment earlier can be taken by another process before the store binds it)."""
+def _run_world(world, tmp_path):
+    """Spawn `world` gloo ranks and return rank 0's result.  Any worker that exits non-zero, or does not finish in time,
+    fails the test: nothing is retried."""
     import queue
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    store_file = str(tmp_path / "gloo_store")
+    procs = [ctx.Process(target=_worker, args=(r, world, store_file, q)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -107,16 +100,16 @@ def _run_world(world):
         if p.is_alive():
             p.kill()
             p.join()
-            got = None
-        elif p.exitcode != 0:
-            got = None
+            pytest.fail("a gloo rank did not finish in time")
+    codes = [p.exitcode for p in procs]
+    assert codes == [0] * world, f"worker exit codes {codes}"
+    assert got is not None, "rank 0 sent no result"
     return got
 
 
-def test_two_rank_step_equals_dataparallel_semantics():
+def test_two_rank_step_equals_dataparallel_semantics(tmp_path):
     world = 2
-    got = _run_world(world) or _run_world(world)             # one retry on a lost port race
-    assert got is not None, "the two gloo ranks did not complete"
+    got = _run_world(world, tmp_path)
     got["arena"] = torch.from_numpy(got["arena"])
 
     # single-process emulation of nn.DataParallel

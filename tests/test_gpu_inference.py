@@ -318,3 +318,33 @@ def test_upsampler_one_launch_kernel_edges(cin, cout, shape):
     torch.cuda.synchronize()
     assert tuple(y.shape) == (shape[0], 2 * shape[2], 2 * shape[3], cout)
     assert rel_err(_back(y), ref) <= 1e-2
+
+
+def test_iou_eval_plane_inputs_vs_golden():
+    """iouEval.addBatch with one-hot / soft-score planes (train/iouEval.py:37-38,45-46 take them as they are): counts of one-hot
+    inputs exact, soft scores to the reference's own fp32 summation error; mixed with a label-map batch in one evaluator."""
+    from erfnet_pytorch_amd.iouEval import iouEval
+    from tests.test_oracle_golden import _plane_cases
+    g = load("g4_iou.npz")
+    for nc in (20, 4):
+        for tag, (x, y) in _plane_cases(nc).items():
+            ev = iouEval(nc)
+            ev.addBatch(x.to(_dev()), y.to(_dev()))
+            ev.addBatch(x.to(_dev()), y.to(_dev()))
+            for k in ("tp", "fp", "fn"):
+                ref = g[f"planes_nc{nc}_{tag}_{k}"]
+                got = getattr(ev, k).numpy()
+                if tag.startswith("onehot"):
+                    assert np.array_equal(got, ref), (nc, tag, k)
+                else:
+                    assert np.allclose(got, ref, rtol=2e-6, atol=1e-6), (nc, tag, k)
+        # a label-map batch and its one-hot form add up to twice the label-map counts
+        x, y = _plane_cases(nc)["onehot_x"]
+        pred = x.argmax(1, keepdim=True)
+        ev, ev2 = iouEval(nc), iouEval(nc)
+        ev.addBatch(pred.to(_dev()), y.to(_dev()))
+        ev.addBatch(x.to(_dev()), y.to(_dev()))
+        ev2.addBatch(pred.to(_dev()), y.to(_dev()))
+        assert torch.equal(ev.tp, 2 * ev2.tp) and torch.equal(ev.fp, 2 * ev2.fp) and torch.equal(ev.fn, 2 * ev2.fn)
+        with pytest.raises(ValueError):
+            iouEval(nc).addBatch(x[:, :-1].to(_dev()), y.to(_dev()))

@@ -552,8 +552,7 @@ def test_trainer_checkpoint_resume_is_interchangeable_with_torch_adam():
     assert trb.step_count == 2
 
 
-@pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 18),      # fp32: the 128-channel layers keep the separate BatchNorm backward
-                                                      
+@pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 28),
                                                       (torch.bfloat16, 8e-2, (1, 512, 1024), 34)])
 def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, expected):
     """The BatchNorm backward whose reductions ride in the preceding data-gradient convolution (in-block bn1, and the
@@ -717,7 +716,7 @@ def test_checkpoint_file_round_trip_through_reference_format(tmp_path):
 def test_fused_head_loss_primitive_vs_torch(nc, dtype, tol):
     """ConvTranspose2d(16, nc, 2, stride 2) + weighted cross entropy as one autograd node (train/erfnet.py:171,179 +
     train/main.py:121,202) against torch's own two ops in fp32: loss, d input, d weight, d bias; every class-count tile
-    variant, labels outside [0, nc) and zero-weight classes included."""
+    variant, ignore_index (-100) labels and zero-weight classes included."""
     from erfnet_pytorch_amd import autograd as ag
     g = torch.Generator().manual_seed(7 + nc)
     n, h, w = 2, 12, 20                                               # 480 input pixels: the last workgroup is partly empty
@@ -727,7 +726,7 @@ def test_fused_head_loss_primitive_vs_torch(nc, dtype, tol):
     cw = torch.rand(nc, generator=g) + 0.5
     cw[nc - 1] = 0.0                                                  # the reference's weight[19] = 0
     t = torch.randint(0, nc, (n, 2 * h, 2 * w), generator=g)
-    t[0, :3, :5] = 255                                                # ignored by value
+    t[0, :3, :5] = -100                                               # torch's ignore_index: carries no weight
     xr = x.to(dtype).float().requires_grad_(True)                     # the same rounded input on both sides
     wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
     logits = torch.nn.functional.conv_transpose2d(xr, wr.to(dtype).float() if dtype == torch.bfloat16 else wr, br, stride=2)
@@ -764,3 +763,58 @@ def test_dropout_masks_of_a_pass_in_one_launch_equal_the_per_layer_masks():
         call("erf_dropout2d_mask", one.data_ptr(), c, float(p), int(s), ops._stream())
         assert torch.equal(many[off:off + c], one)
         off += c
+
+
+def test_second_backward_into_trainer_arena_is_refused():
+    """Kernels overwrite the trainer's gradient arena, so a second backward pass before zero_grad() would replace, not add to,
+    the first one's gradients (torch accumulates): it raises instead of training on wrong gradients."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    m = E.ERFNet(20)
+    m.load_state_dict(O.synthetic_state(O.erfnet_template(20)))
+    m = m.to(DEV).train()
+    tr = Trainer(m, CITYSCAPES_WEIGHTS)
+    x = S.synthetic_images(1, 32, 64, seed=5).to(DEV)
+    t = S.synthetic_labels(1, 32, 64, 20, seed=5).to(DEV)
+    tr.step(x, t)
+    tr.step(x, t)                                   # step() clears the arena first: fine any number of times
+    tr.zero_grad()
+    m(x).sum().backward()                           # one manual pass after zero_grad(): fine
+    with pytest.raises(RuntimeError, match="second backward pass"):
+        m(x).sum().backward()
+    tr.step(x, t)                                   # and the trainer still works afterwards
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_out_of_range_target_poisons_the_loss(fused):
+    """torch.nn.CrossEntropyLoss (train/main.py:121) raises on a target outside [0, C) other than -100 -- e.g. an unmapped
+    Cityscapes 255.  The kernels cannot raise without a host round trip: such a pixel turns the loss and the gradients NaN,
+    in the fused head+loss path and in the stand-alone loss alike; -100 is ignored as in torch."""
+    from erfnet_pytorch_amd import autograd as ag
+    from erfnet_pytorch_amd.loss import CrossEntropyLoss2d
+    g = torch.Generator().manual_seed(3)
+    n, h, w, nc = 1, 8, 12, 20
+    cw = torch.tensor(O.CITYSCAPES_WEIGHTS)
+    t = torch.randint(0, nc, (n, 2 * h, 2 * w), generator=g)
+    x = torch.randn(n, 16, h, w, generator=g).to(DEV)
+    wt, b = (torch.randn(16, nc, 2, 2, generator=g) * 0.3).to(DEV), torch.zeros(nc, device=DEV)
+
+    def run(target):
+        xd = x.clone().requires_grad_(True)
+        if fused:
+            loss = ag._HeadLossFn.apply(xd, wt, b, target.to(DEV), cw.to(DEV), None, None)
+        else:
+            logits = torch.nn.functional.conv_transpose2d(xd, wt, b, stride=2)
+            loss = CrossEntropyLoss2d(cw).to(DEV)(logits, target.to(DEV))
+        loss.backward()
+        return loss.item(), xd.grad
+
+    clean, _ = run(t)
+    t_ign = t.clone(); t_ign[0, 2, 3] = -100
+    ign, gi = run(t_ign)
+    ref = torch.nn.functional.cross_entropy(torch.nn.functional.conv_transpose2d(x.cpu(), wt.cpu(), b.cpu(), stride=2), t_ign, cw)
+    assert np.isfinite(clean) and abs(ign - ref.item()) <= 1e-5 * abs(ref.item()) and torch.isfinite(gi).all()
+    for bad in (255, 20, -1):
+        t_bad = t.clone(); t_bad[0, 5, 7] = bad
+        loss, gb = run(t_bad)
+        assert np.isnan(loss) and torch.isnan(gb).any(), bad

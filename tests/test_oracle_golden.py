@@ -154,6 +154,29 @@ def test_g4_iou_counts_exact():
         assert mean.item() == float(g[f"nc{nc}_iou_mean"])
 
 
+def _plane_cases(nc):
+    from tests.golden_util import upstream
+    pred = S.synthetic_labels(2, 24, 40, nc, seed=471, ignore_frac=0.0)
+    lab = S.synthetic_labels(2, 24, 40, nc, seed=472, ignore_frac=0.07 if nc == 20 else 0.0)
+    onehot = lambda t: torch.zeros(t.size(0), nc, t.size(2), t.size(3)).scatter_(1, t, 1)
+    soft = torch.softmax(3.0 * upstream((2, nc, 24, 40), 473), dim=1)
+    return {"onehot_x": (onehot(pred), lab), "onehot_y": (pred, onehot(lab)), "soft_x": (soft, onehot(lab))}
+
+
+def test_g4_iou_plane_inputs():
+    """addBatch on inputs that already have nClasses planes (train/iouEval.py:37-38,45-46), two calls accumulated."""
+    g = load("g4_iou.npz")
+    for nc in (20, 4):
+        for tag, (x, y) in _plane_cases(nc).items():
+            sums = [2 * v for v in O.iou_plane_sums(x, y, nc)]
+            for k, v in zip(("tp", "fp", "fn"), sums):
+                ref = g[f"planes_nc{nc}_{tag}_{k}"]
+                if tag.startswith("onehot"):
+                    assert np.array_equal(v.numpy(), ref), (nc, tag, k)          # counts: exact
+                else:
+                    assert np.allclose(v.numpy(), ref, rtol=2e-6, atol=1e-6), (nc, tag, k)   # the reference sums in fp32
+
+
 def test_g5_three_train_steps():
     g = load("g5_train_steps.npz")
     sd = O.synthetic_state(O.erfnet_template(20))

@@ -9,7 +9,6 @@ logits, gradients summed.
 """
 import os
 import queue
-import socket
 
 import numpy as np
 import pytest
@@ -20,12 +19,6 @@ from oracle import erfnet_oracle as O
 
 pytestmark = pytest.mark.gpu
 H, W, NC, NB = 64, 128, 20, 2
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def _build(dtype):
@@ -46,14 +39,15 @@ def _shard(rank):
     return x, t
 
 
-def _worker(rank, world, port, dtype, overlap, q):
+def _worker(rank, world, store_file, dtype, overlap, q):
     import torch.distributed as dist
     from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{store_file}", rank=rank, world_size=world)
     from erfnet_pytorch_amd.dp import stage_collectives_through_host
-    stage_collectives_through_host()          # gloo's device-tensor path stalls when two busy processes share one GPU
+    # gloo's own device-tensor all-reduce stalls for tens of seconds when it is issued while this process still has kernels
+    # queued and a second busy process shares the GPU (scripts/hang_probe.py: no stall without gloo, with these host-staged
+    # collectives, or with the device drained first; the same stall with or without any particular kernel of the step)
+    stage_collectives_through_host()
     try:
         torch.cuda.set_device(0)
         m = _build(dtype)
@@ -67,12 +61,12 @@ def _worker(rank, world, port, dtype, overlap, q):
         dist.destroy_process_group()
 
 
-def _run(world, dtype, overlap):
+def _run(world, dtype, overlap, tmp_path, worker=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, overlap, q)) for r in range(world)]
+    store_file = str(tmp_path / "store")
+    procs = [ctx.Process(target=worker or _worker, args=(r, world, store_file, dtype, overlap, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -91,12 +85,12 @@ def _run(world, dtype, overlap):
     return got
 
 
-@pytest.mark.parametrize("dtype,overlap,tol", [("bf16", True, 8e-2), ("bf16", False, 8e-2), ("fp32", True, 1e-4)])
-def test_two_rank_trainer_step_equals_dataparallel_semantics(dtype, overlap, tol):
+@pytest.mark.parametrize("dtype,overlap,tol", [("bf16", True, 8e-2), ("bf16", False, 8e-2), ("fp32", True, 1e-4), ("fp32", False, 1e-4)])
+def test_two_rank_trainer_step_equals_dataparallel_semantics(dtype, overlap, tol, tmp_path):
     from erfnet_pytorch_amd.loss import CrossEntropyLoss2d
     from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
     world = 2
-    got = _run(world, dtype, overlap)
+    got = _run(world, dtype, overlap, tmp_path)
     # replicas stay identical: same reduced gradients, same parameters after Adam, same (global) loss
     assert got[0][0] == got[1][0]
     assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
@@ -126,3 +120,39 @@ def test_two_rank_trainer_step_equals_dataparallel_semantics(dtype, overlap, tol
         err = (g - pg).norm().item() / max(pg.norm().item(), 1e-12)
         worst = max(worst, err)
         assert err <= tol, (k, err)
+
+
+def _rccl_worker(rank, world, store_file, dtype, overlap, q):
+    """One rank, backend nccl (= RCCL): the production collective path on a single GPU."""
+    import torch.distributed as dist
+    from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{store_file}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x, t = _shard(0)
+        res = []
+        for group in (dist.group.WORLD, None):
+            tr = Trainer(_build(dtype), CITYSCAPES_WEIGHTS, group=group, world_size=1, overlap=overlap, force_collectives=True)
+            assert tr.collective == (group is not None) and tr.overlap == (overlap and group is not None)
+            losses = []
+            for _ in range(2):
+                loss, _ = tr.step(x, t)
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            res.append((losses, tr.gflat.cpu().numpy().copy(), tr.flat.cpu().numpy().copy()))
+        q.put((0, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,overlap", [("bf16", True), ("bf16", False), ("fp32", True)])
+def test_collective_path_on_rccl_with_one_rank_is_bit_identical_to_no_group(dtype, overlap, tmp_path):
+    """The asynchronous device-tensor all-reduces of the production path (three gradient buckets launched from the autograd
+    thread behind the kernels of the raw current stream, the 2-float loss all-reduce, Work.wait() before Adam) on RCCL with a
+    one-rank group: sums over one rank change nothing, so two optimisation steps must match the group-less run bit for bit."""
+    got = _run(1, dtype, overlap, tmp_path, worker=_rccl_worker)
+    (l_a, g_a, p_a), (l_b, g_b, p_b) = got[0][0]
+    assert l_a == l_b
+    assert np.array_equal(g_a, g_b) and np.array_equal(p_a, p_b)
