@@ -53,18 +53,75 @@ DECODER_LAYERS = [("up", 128, 64, 0.0, 1), ("nb", 64, 64, 0.0, 1), ("nb", 64, 64
                   ("up", 64, 16, 0.0, 1), ("nb", 16, 16, 0.0, 1), ("nb", 16, 16, 0.0, 1)]
 
 
+class _RoundSTE(torch.autograd.Function):
+    """Storage rounding of an activation: the value is rounded to `dtype` on the way forward and the gradient that flows back
+    through the same tensor is rounded too (an engine that keeps its feature maps in bf16 keeps their gradients in bf16)."""
+
+    @staticmethod
+    def forward(ctx, t, dtype, fwd, bwd):
+        ctx.dtype, ctx.bwd = dtype, bwd
+        return t.to(dtype).to(t.dtype) if fwd else t.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dtype).to(g.dtype) if ctx.bwd else g), None, None, None
+
+
 class RunState:
-    """Mode switches and side channels of one forward pass."""
+    """Mode switches and side channels of one forward pass.
+
+    `storage_dtype` (default None = the reference's arithmetic, which is what the golden vectors pin): when set to
+    torch.bfloat16 the SAME graph is evaluated with every stored feature map, every convolution weight and every feature-map
+    gradient rounded to that type at the point an engine with bf16 storage and fp32 accumulation rounds them -- the yardstick
+    for the bf16 kernels.  `record_gates`: collect, per ReLU / max-pool decision tensor, the smallest distance of a
+    pre-activation from its decision boundary relative to the tensor's rms (`gate_margins`), so that a test can tell whether
+    its input has a decision that rounding noise could flip."""
 
     def __init__(self, training: bool = False, dropout_masks: Optional[Dict[str, torch.Tensor]] = None,
-                 update_running: bool = True, encoder_dropout: Optional[Dict[int, float]] = None):
+                 update_running: bool = True, encoder_dropout: Optional[Dict[int, float]] = None,
+                 storage_dtype: Optional[torch.dtype] = None, record_gates: bool = False):
         self.training = training
+        self.storage_dtype = storage_dtype
+        self.record_gates = record_gates
+        self.gate_margins: List[Tuple[str, float]] = []
         # prefix -> [N,C,1,1] multiplier (already scaled by 1/(1-p)); when absent in
         # training mode the oracle draws a mask with torch's RNG like nn.Dropout2d
         self.dropout_masks = dropout_masks if dropout_masks is not None else {}
         self.update_running = update_running
         self.new_running: Dict[str, torch.Tensor] = {}
         self.used_masks: Dict[str, torch.Tensor] = {}
+
+    # -- storage-rounding hooks (identity unless storage_dtype is set) ----------------------------------------------------
+    def r(self, t):
+        """a stored feature map (value and gradient rounded)"""
+        return t if self.storage_dtype is None else _RoundSTE.apply(t, self.storage_dtype, True, True)
+
+    def w(self, t):
+        """a convolution weight as the matrix units see it (rounded copy; the gradient reaches the fp32 master unchanged)"""
+        return t if self.storage_dtype is None else _RoundSTE.apply(t, self.storage_dtype, True, False)
+
+    def g(self, t):
+        """a tensor kept in fp32 whose GRADIENT is stored rounded (the logits)"""
+        return t if self.storage_dtype is None else _RoundSTE.apply(t, self.storage_dtype, False, True)
+
+    def relu(self, name, t):
+        if self.record_gates:
+            rms = float(t.detach().double().pow(2).mean().sqrt())
+            a = t.detach().abs()
+            a = a[a > 0]                       # an exact zero (zero input under a dropped channel) is a reproducible decision
+            self.gate_margins.append((name, (float(a.min()) if a.numel() else float("inf")) / max(rms, 1e-30)))
+        return F.relu(t)
+
+    def note_pool(self, name, x):
+        """2x2 max-pool routing: margin = smallest gap between the two largest values of a window"""
+        if self.record_gates:
+            n, c, h, w = x.shape
+            win = x.detach().reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+            top = win.topk(2, dim=-1).values
+            rms = float(x.detach().double().pow(2).mean().sqrt())
+            gap = top[..., 0] - top[..., 1]
+            gap = gap[gap > 0]                 # an exact tie goes to the first maximum in every implementation
+            self.gate_margins.append((name, (float(gap.min()) if gap.numel() else float("inf")) / max(rms, 1e-30)))
 
 
 def _bn(sd: SD, p: str, x: torch.Tensor, st: RunState) -> torch.Tensor:
@@ -83,18 +140,23 @@ def _bn(sd: SD, p: str, x: torch.Tensor, st: RunState) -> torch.Tensor:
 
 
 def downsampler(sd: SD, p: str, x: torch.Tensor, st: RunState) -> torch.Tensor:
-    conv = F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=2, padding=1)
+    # the 3-channel initial block reads the fp32 image with fp32 weights; every other layer's weights are stored rounded
+    wt = sd[p + ".conv.weight"] if x.shape[1] == 3 else st.w(sd[p + ".conv.weight"])
+    conv = F.conv2d(x, wt, sd[p + ".conv.bias"], stride=2, padding=1)
+    st.note_pool(p + ".pool", x)
     pool = F.max_pool2d(x, 2, stride=2)
-    return F.relu(_bn(sd, p + ".bn", torch.cat([conv, pool], 1), st))
+    z = st.r(torch.cat([conv, pool], 1))
+    return st.r(st.relu(p + ".relu", _bn(sd, p + ".bn", z, st)))
 
 
 def nb1d(sd: SD, p: str, x: torch.Tensor, dilation: int, dropprob: float, st: RunState) -> torch.Tensor:
     d = dilation
-    y = F.relu(F.conv2d(x, sd[p + ".conv3x1_1.weight"], sd[p + ".conv3x1_1.bias"], padding=(1, 0)))
-    y = F.conv2d(y, sd[p + ".conv1x3_1.weight"], sd[p + ".conv1x3_1.bias"], padding=(0, 1))
-    y = F.relu(_bn(sd, p + ".bn1", y, st))
-    y = F.relu(F.conv2d(y, sd[p + ".conv3x1_2.weight"], sd[p + ".conv3x1_2.bias"], padding=(d, 0), dilation=(d, 1)))
-    y = F.conv2d(y, sd[p + ".conv1x3_2.weight"], sd[p + ".conv1x3_2.bias"], padding=(0, d), dilation=(1, d))
+    y = st.r(st.relu(p + ".relu1", F.conv2d(x, st.w(sd[p + ".conv3x1_1.weight"]), sd[p + ".conv3x1_1.bias"], padding=(1, 0))))
+    y = st.r(F.conv2d(y, st.w(sd[p + ".conv1x3_1.weight"]), sd[p + ".conv1x3_1.bias"], padding=(0, 1)))
+    y = st.r(st.relu(p + ".relu2", _bn(sd, p + ".bn1", y, st)))
+    y = st.r(st.relu(p + ".relu3", F.conv2d(y, st.w(sd[p + ".conv3x1_2.weight"]), sd[p + ".conv3x1_2.bias"], padding=(d, 0),
+                                            dilation=(d, 1))))
+    y = st.r(F.conv2d(y, st.w(sd[p + ".conv1x3_2.weight"]), sd[p + ".conv1x3_2.bias"], padding=(0, d), dilation=(1, d)))
     y = _bn(sd, p + ".bn2", y, st)
     if dropprob != 0 and st.training:
         if p in st.dropout_masks:
@@ -104,12 +166,12 @@ def nb1d(sd: SD, p: str, x: torch.Tensor, dilation: int, dropprob: float, st: Ru
             m = keep / (1.0 - dropprob)
         st.used_masks[p] = m
         y = y * m
-    return F.relu(y + x)
+    return st.r(st.relu(p + ".relu4", y + x))
 
 
 def upsampler(sd: SD, p: str, x: torch.Tensor, st: RunState) -> torch.Tensor:
-    y = F.conv_transpose2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=2, padding=1, output_padding=1)
-    return F.relu(_bn(sd, p + ".bn", y, st))
+    y = st.r(F.conv_transpose2d(x, st.w(sd[p + ".conv.weight"]), sd[p + ".conv.bias"], stride=2, padding=1, output_padding=1))
+    return st.r(st.relu(p + ".relu", _bn(sd, p + ".bn", y, st)))
 
 
 def _run_layers(sd: SD, prefix: str, layers, x: torch.Tensor, st: RunState, dropout_override=None) -> torch.Tensor:
@@ -129,13 +191,13 @@ def encoder(sd: SD, x: torch.Tensor, st: RunState, predict: bool = False, prefix
     x = downsampler(sd, prefix + ".initial_block", x, st)
     x = _run_layers(sd, prefix, ENCODER_LAYERS, x, st, dropout_override)
     if predict:
-        x = F.conv2d(x, sd[prefix + ".output_conv.weight"], sd[prefix + ".output_conv.bias"])
+        x = st.g(F.conv2d(x, st.w(sd[prefix + ".output_conv.weight"]), sd[prefix + ".output_conv.bias"]))
     return x
 
 
 def decoder(sd: SD, x: torch.Tensor, st: RunState, prefix: str = "decoder") -> torch.Tensor:
     x = _run_layers(sd, prefix, DECODER_LAYERS, x, st)
-    return F.conv_transpose2d(x, sd[prefix + ".output_conv.weight"], sd[prefix + ".output_conv.bias"], stride=2)
+    return st.g(F.conv_transpose2d(x, st.w(sd[prefix + ".output_conv.weight"]), sd[prefix + ".output_conv.bias"], stride=2))
 
 
 def erfnet(sd: SD, x: torch.Tensor, st: Optional[RunState] = None, only_encode: bool = False) -> torch.Tensor:
@@ -301,12 +363,12 @@ def sgd_step(params, grads, bufs, lr=0.1, momentum=0.9, weight_decay=1e-4):
 
 # ----------------------------------------------------------------------------- training step helpers
 
-def train_step_grads(sd: SD, images, target, weight, masks=None, num_classes=20, only_encode=False):
+def train_step_grads(sd: SD, images, target, weight, masks=None, num_classes=20, only_encode=False, storage_dtype=None):
     """One forward/backward in training mode.  Returns (loss, grads dict, new running stats, used masks).
     `only_encode`: the encoder stage of the recipe (train/main.py:203, `model(inputs, only_encode=enc)`)."""
     leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
             for k, v in sd.items()}
-    st = RunState(training=True, dropout_masks=masks)
+    st = RunState(training=True, dropout_masks=masks, storage_dtype=storage_dtype)
     logits = erfnet(leaf, images, st, only_encode=only_encode)
     loss = weighted_ce(logits, target, weight)
     loss.backward()

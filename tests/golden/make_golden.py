@@ -388,6 +388,94 @@ def g8_multi_models():
     np.savez_compressed(os.path.join(HERE, "g8_multi_models.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G9
+def _oracle_margin(kind, prefix, sd, x, args, masks, storage_dtype):
+    """Smallest relative distance of a ReLU / max-pool decision from its boundary, from the oracle's evaluation of the
+    same block (same torch ops in the same order as the reference module).  Exact zeros / exact ties are reproducible
+    decisions (zero inputs, dropped channels), not fragile ones, and are skipped by the recorder's caller below."""
+    from oracle import erfnet_oracle as O
+    st = O.RunState(training=True, dropout_masks=masks, storage_dtype=storage_dtype, record_gates=True)
+    xx = x.to(storage_dtype).float() if (storage_dtype is not None and x.shape[1] != 3) else x
+    with torch.no_grad():
+        if kind == "nb":
+            y = O.nb1d(sd, prefix, xx, args[1], args[2], st)
+        elif kind == "down":
+            y = O.downsampler(sd, prefix, xx, st)
+        else:
+            y = O.upsampler(sd, prefix, xx, st)
+    return min(m for _, m in st.gate_margins), y
+
+
+def g9_gate_safe_blocks():
+    """Block fixtures whose every ReLU gate and max-pool route is DECISIVE: the search below walks seeds until no
+    pre-activation of the reference lies within MARGIN (relative to its tensor's rms) of a decision boundary, both in the
+    reference's own fp32 arithmetic and in the same graph evaluated with bf16 storage.  Two correct implementations then
+    take identical decisions, and gradients can be compared element by element in max-norm with no outlier allowance.
+    Tensors are stored in full."""
+    global MAX_FULL
+    from oracle import erfnet_oracle as O
+    keep, MAX_FULL = MAX_FULL, 1 << 30
+    MARGIN = 2e-5
+    out = {"margin_required": np.array(MARGIN)}
+    cases = [("nb", (64, 1, 0.03), (2, 64, 8, 24)), ("nb", (16, 1, 0.0), (1, 16, 16, 32)), ("nb", (128, 2, 0.3), (2, 128, 8, 16)),
+             ("nb", (128, 4, 0.3), (1, 128, 16, 16)), ("nb", (128, 8, 0.3), (1, 128, 24, 16)), ("nb", (128, 16, 0.3), (1, 128, 40, 8)),
+             ("down", (16, 64), (1, 16, 16, 32)), ("down", (64, 128), (1, 64, 16, 16)), ("down", (3, 16), (1, 3, 16, 32)),
+             ("up", (128, 64), (1, 128, 8, 8)), ("up", (64, 16), (1, 64, 8, 16))]
+    for kind, args, shape in cases:
+        tag = f"{kind}_" + "_".join(str(int(a * 100) if isinstance(a, float) else a) for a in args)
+        found = None
+        for seed in range(1000, 3000):
+            prefix = f"safe{seed}" if kind != "up" else f"decoder.layers.{seed}"
+            if kind == "nb":
+                mod = ref_erfnet.non_bottleneck_1d(args[0], args[2], args[1])
+            elif kind == "down":
+                mod = ref_erfnet.DownsamplerBlock(*args)
+            else:
+                mod = ref_erfnet.UpsamplerBlock(*args)
+            sd = S.fill_state_dict({prefix + "." + k: v for k, v in mod.state_dict().items()})
+            x = S.synthetic_images(shape[0], shape[2], shape[3], seed=seed) if shape[1] == 3 else activations(shape, seed)
+            masks = {}
+            if kind == "nb" and args[2] > 0:
+                torch.manual_seed(1234 + seed)
+                keepm = (torch.rand(shape[0], shape[1], 1, 1) >= args[2]).float()
+                masks = {prefix: keepm / (1.0 - args[2])}
+            m32, _ = _oracle_margin(kind, prefix, sd, x, args, masks, None)
+            if m32 < MARGIN:
+                continue
+            m16, _ = _oracle_margin(kind, prefix, sd, x, args, masks, torch.bfloat16)
+            if m16 < MARGIN:
+                continue
+            found = (seed, prefix, mod, sd, x, masks, m32, m16)
+            break
+        assert found is not None, tag
+        seed, prefix, mod, sd, x, masks, m32, m16 = found
+        print(tag, "seed", seed, "margins", m32, m16)
+        mod.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items()})
+        mod.train()
+        if masks:        # make the reference's Dropout2d apply exactly this mask
+            mk = masks[prefix]
+            mod.dropout.forward = lambda t, mk=mk: t * mk
+        xr = x.clone().requires_grad_(True)
+        y = mod(xr)
+        dy = upstream(y.shape, seed)
+        y.backward(dy)
+        out[tag + "__prefix"] = np.array(prefix)
+        out[tag + "__xshape"] = np.array(x.shape, dtype=np.int64)
+        out[tag + "__seed"] = np.array(seed, dtype=np.int64)
+        out[tag + "__margins"] = np.array([m32, m16])
+        pack(out, tag + "_y_train", y)
+        pack(out, tag + "_dx", xr.grad)
+        for k, v in mod.named_parameters():
+            pack(out, tag + "_grad_" + k, v.grad)
+        for k, v in mod.named_buffers():
+            if "num_batches" not in k:
+                pack(out, tag + "_buf_" + k, v)
+        if masks:
+            out[tag + "_mask"] = masks[prefix].numpy()
+    MAX_FULL = keep
+    np.savez_compressed(os.path.join(HERE, "g9_gate_safe_blocks.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # e.g. `make_golden.py g7_encoder_only`: regenerate the named sets only
         for name in sys.argv[1:]:
@@ -401,6 +489,7 @@ if __name__ == "__main__":
     g6_imagenet()
     g7_encoder_only()
     g8_multi_models()
+    g9_gate_safe_blocks()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -8,7 +8,7 @@ import torch
 
 from erfnet_pytorch_amd import synthetic as S
 from oracle import erfnet_oracle as O
-from tests.golden_util import load, check_packed, activations, upstream, pre_bn_bias
+from tests.golden_util import load, check_packed, activations, upstream, pre_bn_bias, rel_err
 
 TOL = 2e-6
 torch.set_num_threads(8)
@@ -319,3 +319,51 @@ def test_g6_imagenet_encoder_classifier():
     O.sgd_step(params, [leaf[k].grad for k in names], bufs)
     ps = np.array([p.double().sum().item() for p in params])
     assert np.allclose(ps, g["paramsum"], rtol=1e-4, atol=1e-4)
+
+
+def _g9_tags():
+    g = load("g9_gate_safe_blocks.npz")
+    return sorted({k.split("__prefix")[0] for k in g.files if k.endswith("__prefix")})
+
+
+@pytest.mark.parametrize("tag", _g9_tags())
+def test_g9_gate_safe_blocks(tag):
+    """The oracle on the decisive-gate fixtures: outputs and every gradient against the reference's, element by element;
+    the recorded decision margins are reproduced (fp32 and bf16-storage evaluation), i.e. the fixtures are what they claim."""
+    from tests.golden_util import unpack_full, activations, upstream, pre_bn_bias
+    g = load("g9_gate_safe_blocks.npz")
+    prefix = str(g[tag + "__prefix"])
+    shape = tuple(int(v) for v in g[tag + "__xshape"])
+    seed = int(g[tag + "__seed"])
+    parts = tag.split("_")
+    if parts[0] == "nb":
+        c, d, p = int(parts[1]), int(parts[2]), int(parts[3]) / 100.0
+        tmpl, fwd = O.nb_template(prefix, c), (lambda sd, xx, st: O.nb1d(sd, prefix, xx, d, p, st))
+    elif parts[0] == "down":
+        tmpl, fwd = O.down_template(prefix, int(parts[1]), int(parts[2])), (lambda sd, xx, st: O.downsampler(sd, prefix, xx, st))
+    else:
+        tmpl, fwd = O.up_template(prefix, int(parts[1]), int(parts[2])), (lambda sd, xx, st: O.upsampler(sd, prefix, xx, st))
+    x = S.synthetic_images(shape[0], shape[2], shape[3], seed=seed) if shape[1] == 3 else activations(shape, seed)
+    sd = O.synthetic_state(tmpl)
+    masks = {prefix: torch.from_numpy(g[tag + "_mask"])} if (tag + "_mask") in g.files else {}
+    need = float(g["margin_required"])
+    for storage in (None, torch.bfloat16):
+        leaf = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running" not in k) else v) for k, v in sd.items()}
+        st = O.RunState(training=True, dropout_masks=masks, storage_dtype=storage, record_gates=True)
+        xin = x if (storage is None or shape[1] == 3) else x.bfloat16().float()
+        xr = xin.clone().requires_grad_(True)
+        y = fwd(leaf, xr, st)
+        y.backward(upstream(tuple(y.shape), seed))
+        assert min(m for _, m in st.gate_margins) >= 0.5 * need
+        tol = 2e-5 if storage is None else 3e-2          # bf16 storage vs the fp32 reference: rounding of every stored tensor
+        assert rel_err(y.detach(), unpack_full(g, tag + "_y_train")) <= tol
+        if storage is not None:
+            continue          # gradients under bf16 storage are the GPU test's yardstick; against fp32 they differ by design
+                              # (values that tie after rounding route a max-pool gradient to another element)
+        if shape[1] != 3:
+            assert rel_err(xr.grad, unpack_full(g, tag + "_dx")) <= (tol if storage is None else 6e-2)
+        for k, v in leaf.items():
+            if v.requires_grad:
+                name = k[len(prefix) + 1:]
+                assert rel_err(v.grad, unpack_full(g, tag + "_grad_" + name), floor=30.0 if pre_bn_bias(name) else 0.0) <= \
+                    (tol if storage is None else 6e-2), name
