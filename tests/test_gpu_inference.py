@@ -199,29 +199,43 @@ def test_full_net_fp32_vs_golden(nc, tags):
             check_packed(g, "nc20_a_encoder_feat", model.encoder(x).float().cpu(), FP32_TOL)
 
 
-def test_full_net_bf16_vs_oracle():
+BF16_LOGIT_TOL = 6e-2        # stated bf16 tolerance on logits, relative to the largest logit magnitude of the reference
+
+
+@pytest.mark.parametrize("nc,tags", [(20, ("a", "b")), (6, ("a",))])
+def test_full_net_bf16_vs_golden(nc, tags):
+    """bf16 activations / weights with fp32 accumulation against the REFERENCE's fp32 outputs: logits within the stated bf16
+    tolerance, and labels EXACT wherever the reference's own top-2 margin exceeds twice that tolerance (a smaller margin cannot
+    be decided by any bf16 evaluation) -- the same rule the fp32 test applies with its 1e-4."""
     from erfnet_pytorch_amd import erfnet as E
-    sd = O.synthetic_state(O.erfnet_template(20))
-    model = E.ERFNet(20)
-    model.load_state_dict(sd)
+    g = load("g1_full_eval.npz")
+    model = E.ERFNet(nc)
+    model.load_state_dict(O.synthetic_state(O.erfnet_template(nc)))
     model = model.to(_dev()).eval()
     model.compute_dtype = torch.bfloat16
-    x = S.synthetic_images(2, 128, 256, seed=7)
-    with torch.no_grad():
-        ref = O.erfnet(sd, x)
-        y = model(x.to(_dev()))
-        labels = model.predict_labels(x.to(_dev()))
-    assert y.dtype == torch.float32
-    err = rel_err(y.cpu(), ref)
-    assert err <= 6e-2, err
-    agree = (labels.cpu() == ref.max(1)[1]).float().mean().item()
-    assert agree > 0.90, agree                                        # stated bf16 label agreement on synthetic weights
-    assert torch.equal(labels.cpu(), y.cpu().max(1)[1])
+    for tag in tags:
+        n, h, w, seed = (int(v) for v in g[f"nc{nc}_{tag}__in"])
+        x = S.synthetic_images(n, h, w, seed=seed).to(_dev())
+        with torch.no_grad():
+            y = model(x)
+            labels = model.predict_labels(x)
+        assert y.dtype == torch.float32
+        check_packed(g, f"nc{nc}_{tag}_logits", y.cpu(), BF16_LOGIT_TOL)
+        lab = labels.cpu()
+        assert torch.equal(lab, y.cpu().max(1)[1])                 # fused arg-max == arg-max of our logits
+        gold = torch.from_numpy(g[f"nc{nc}_{tag}_argmax"].astype(np.int64))
+        margin = torch.from_numpy(g[f"nc{nc}_{tag}_margin"])
+        amax = float(np.abs(g[f"nc{nc}_{tag}_logits__sample"]).max())
+        decided = margin > 2 * BF16_LOGIT_TOL * amax
+        assert decided.float().mean().item() > 0.1                 # the rule binds a real share of the pixels (19 % .. 40 %)
+        assert torch.equal(lab[decided], gold[decided]), "bf16 labels differ where the reference margin is decisive"
+        assert (lab == gold).float().mean().item() > 0.90          # overall agreement on these random-weight logits, for the record
 
 
-@pytest.mark.parametrize("nc,shape", [(20, (2, 512, 1024)), (6, (1, 1024, 2048))])
+@pytest.mark.parametrize("nc,shape", [(20, (16, 512, 1024)), (6, (8, 1024, 2048))])
 def test_full_size_properties(nc, shape):
-    """The benchmark configurations at their full sizes (the oracle takes seconds per image there), through properties
+    """BASELINE configs[1] (batch 16, 3x512x1024, 20 classes) and configs[4] (batch 8, 3x1024x2048, 6 classes) at their
+    full sizes (the oracle takes seconds per image there), through properties
     that do not depend on the size: fused labels == arg-max of the logits path bit for bit, images of a batch are
     independent (same result alone and in a batch), the confusion matrix counts every pixel once and equals the
     histogram of (label, prediction) pairs computed by torch."""
@@ -236,10 +250,11 @@ def test_full_size_properties(nc, shape):
     with torch.no_grad():
         logits = model(x)
         labels = model.predict_labels(x, torch.uint8)
-        alone = model.predict_labels(x[:1].contiguous(), torch.uint8)
+        alone = model.predict_labels(x[n - 1:].contiguous(), torch.uint8)
     assert logits.shape == (n, nc, h, w) and labels.shape == (n, h, w)
     assert torch.equal(labels.long(), logits.max(1)[1])
-    assert torch.equal(alone[0], labels[0])
+    assert torch.equal(alone[0], labels[n - 1])
+    del logits
     target = S.synthetic_labels(n, h, w, nc, seed=12).to(_dev())
     ev = iouEval(nc)
     ev.addBatch(labels.unsqueeze(1), target)
