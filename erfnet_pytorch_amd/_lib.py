@@ -66,6 +66,7 @@ SIGNATURES = {
     "erf_conv1d_dgrad_bn_backward": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P, P, P, P]),
     "erf_conv1d_pack_many": (I, [P, I, I, I, P]),
     "erf_conv1d_pair": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "erf_nb1d_block_infer": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "erf_downsampler_packed_bytes": (c_size_t, [I, I, I]),
     "erf_downsampler_pack": (I, [P, P, I, I, I, P]),
     "erf_downsampler": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),

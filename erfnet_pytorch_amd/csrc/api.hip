@@ -68,6 +68,15 @@ int erf_conv1d_pair(const void* x, void* y, const void* packed_a, const void* pa
                               relu, (hipStream_t)stream);
 }
 
+int erf_nb1d_block_infer(const void* x, void* y, const void* packed1, const void* packed2, const void* packed3, const void* packed4,
+                         const float* table, int dtype, int N, int H, int W, int C, int dilation, void* stream) {
+    if (!x || !y || !packed1 || !packed2 || !packed3 || !packed4 || !table || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 ||
+        dilation < 1 || x == y)
+        return ERF_EINVAL;
+    const void* const packed[4] = {packed1, packed2, packed3, packed4};
+    return nb1d_block_launch(x, y, packed, table, dtype, N, H, W, C, dilation, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ DownsamplerBlock
 size_t erf_downsampler_packed_bytes(int dtype, int Cin, int Cout) {
     if (!dtype_ok(dtype) || Cin <= 0 || Cout <= Cin) return 0;

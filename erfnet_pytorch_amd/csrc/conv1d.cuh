@@ -29,3 +29,9 @@ int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* s
                       const void* gate, double* stats, int* groups, int dtype, int N, int H, int W, int C, int axis, int dilation,
                       int relu, hipStream_t stream, const Conv1dBnTail* tail = nullptr);
 int conv1d_buf_max_groups();
+
+// A whole non_bottleneck_1d block (four factorized convolutions, folded BatchNorms, residual) in one launch: bf16, C = 64,
+// dilation 1 (nb1d_block.hip).  packed4: the four mode-0 packed weights; tab: [4][scale | shift][C] fp32 in device memory.
+// ERF_EUNSUPPORTED for every other shape (nothing launched).
+int nb1d_block_launch(const void* x, void* y, const void* const* packed4, const float* tab, int dtype, int N, int H, int W, int C,
+                      int dilation, hipStream_t stream);

@@ -24,6 +24,7 @@ from ._lib import AXIS_H, AXIS_W, BF16, F32
 
 BN_EPS = 1e-3
 FUSE_PAIRS = True     # inference: one launch per conv3x1 -> conv1x3 pair where the library supports it
+FUSE_BLOCKS = False   # inference: one launch per whole non_bottleneck_1d block (bit-identical to the pair path, measured slower: opt-in)
 
 
 def _versions(mod: nn.Module):
@@ -119,7 +120,11 @@ class non_bottleneck_1d(_Block):
     def _prepare(self, code):
         s2, t2 = _bn_affine(self.bn1, self.conv1x3_1.bias)
         s4, t4 = _bn_affine(self.bn2, self.conv1x3_2.bias)
+        b1, b3 = self.conv3x1_1.bias.detach().float(), self.conv3x1_2.bias.detach().float()
+        one = torch.ones_like(b1)
         return {
+            # [4 convolutions][scale | shift][C] for the one-launch block kernel
+            "table": torch.stack([one, b1, s2, t2, one, b3, s4, t4]).contiguous(),
             "w1": ops.pack_conv1d(self.conv3x1_1.weight, code), "t1": self.conv3x1_1.bias.detach().float().contiguous(),
             "w2": ops.pack_conv1d(self.conv1x3_1.weight, code), "s2": s2, "t2": t2,
             "w3": ops.pack_conv1d(self.conv3x1_2.weight, code), "t3": self.conv3x1_2.bias.detach().float().contiguous(),
@@ -129,6 +134,10 @@ class non_bottleneck_1d(_Block):
     def forward_nhwc(self, x):
         c = self._cached(ops.dt(x))
         d = self.dilated
+        if FUSE_BLOCKS:
+            z = ops.nb1d_block(x, (c["w1"], c["w2"], c["w3"], c["w4"]), c["table"], d)
+            if z is not None:
+                return z
         y = ops.conv1d_pair(x, c["w1"], c["t1"], c["w2"], c["s2"], c["t2"], None, 1) if FUSE_PAIRS else None
         if y is None:
             y = ops.conv1d(x, c["w1"], None, c["t1"], None, AXIS_H, 1, True)

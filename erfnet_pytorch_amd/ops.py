@@ -262,6 +262,20 @@ def conv1d_pair(x, packed_a, shift_a, packed_b, scale_b, shift_b, residual, dila
     return y
 
 
+def nb1d_block(x, packed4, table, dilation: int, out=None):
+    """A whole non_bottleneck_1d block (eval mode, BatchNorms folded) in one launch.  Returns None when the library does not
+    take the shape (the caller then issues the two conv1d_pair launches)."""
+    n, h, w, c = x.shape
+    y = torch.empty_like(x) if out is None else out
+    rc = query("erf_nb1d_block_infer", x.data_ptr(), y.data_ptr(), packed4[0].data_ptr(), packed4[1].data_ptr(), packed4[2].data_ptr(),
+               packed4[3].data_ptr(), table.data_ptr(), dt(x), n, h, w, c, dilation, _stream())
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError(f"erf_nb1d_block_infer failed with status {rc}")
+    return y
+
+
 def downsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None):
     n, h, w, cin = x.shape
     y = torch.empty((n, h // 2, w // 2, cout), dtype=x.dtype, device=x.device) if out is None else out

@@ -69,6 +69,19 @@ int erf_conv1d_pair(const void* x, void* y, const void* packed_a, const void* pa
                     const float* shift_a, const float* scale_b, const float* shift_b, const void* residual, int dtype,
                     int N, int H, int W, int C, int dilation, int relu, void* stream);
 
+/* The whole of non_bottleneck_1d.forward in one launch (inference; train/erfnet.py:58-74 with both BatchNorms in eval mode
+ * folded into scale / shift, Dropout2d the identity):
+ *     a1 = relu(conv3x1(x) + t1); a2 = relu(s2 * conv1x3(a1) + t2); a3 = relu(conv3x1_d(a2) + t3);
+ *     y  = relu(s4 * conv1x3_d(a3) + t4 + x)
+ * x is read once and y written once; the three intermediate maps stay on the chip.  Results are bit-identical to two
+ * erf_conv1d_pair calls.  packed1..4: mode-0 packed weights of the four convolutions; table: fp32 [4][2][C] in device memory,
+ * row k = {scale of convolution k (1 where it has none), shift of convolution k}.  x and y must not alias.
+ * Takes bf16, C = 64, dilation 1; returns ERF_EUNSUPPORTED (-2) without launching otherwise: issue two erf_conv1d_pair.
+ * The result is bit-identical to those two launches; on MI355X it currently takes longer than they do (one wave per SIMD
+ * cannot hide its own epilogues), so prefer it only where the number of launches matters. */
+int erf_nb1d_block_infer(const void* x, void* y, const void* packed1, const void* packed2, const void* packed3, const void* packed4,
+                         const float* table, int dtype, int N, int H, int W, int C, int dilation, void* stream);
+
 /* ---- DownsamplerBlock, train/erfnet.py:11-22 ------------------------------------------
  * y[..., :Cout-Cin] = conv3x3 s2 p1 (x), y[..., Cout-Cin:] = maxpool2x2 (x), then
  * y = act(scale * y + shift) over all Cout channels (concat happens on write).
