@@ -3,18 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Headline (`value`), every N: BASELINE.json configs[1] -- ERFNet(20) inference, batch 16 per GPU, bf16
-  activations with fp32 accumulation, 3x512x1024 synthetic images resident in HBM, fused arg-max and
-  the iouEval confusion histogram; one step = one batch through the whole pipeline, replayed from a
-  HIP graph.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own
-  shard of images -- the path has no exchange step, so there is no collective in it ("weak" scaling).
-  The line also carries the roofline of the dominant kernel (measured here with events on the launch
-  stream) and, at N = 1, the CPU baseline (the oracle's fp32 forward, b=1, timed on this box's host
-  cores with the eval_forwardTime protocol).
-"training" object, every N: BASELINE.json configs[2] -- data-parallel training, batch 6 per GPU,
-  weighted cross-entropy, Adam, gradient all-reduce over RCCL inside the timed region; see
-  `trainer.bench_train`.  `--mode train` makes that leg the headline instead.
-Rank 0 prints exactly one JSON line.
+N = 1, headline (`value`): BASELINE.json configs[1] -- ERFNet(20) inference, batch 16, bf16 activations with fp32
+  accumulation, 3x512x1024 synthetic images resident in HBM, fused arg-max and the iouEval confusion histogram; one
+  step = one batch through the whole pipeline, replayed from a HIP graph.  The same line carries
+    "training"       BASELINE.json configs[2]: the bf16 training step, batch 6 (its own steps / warm-up),
+    "fp32"           {"inference", "training"}: the same two legs with fp32 storage (short legs),
+    "roofline"       the dominant kernel alone, timed here with events on the launch stream,
+    "roofline_block" the same measurement priced per non_bottleneck_1d block against the block's algorithmic bytes
+                     (x in, y out), which shows what the two-launch block spends above the one-pass model,
+    "cpu_baseline"   the oracle's fp32 forward, b=1, on this box's host cores (eval_forwardTime protocol).
+N > 1 (launched by torch.distributed.run, one rank per GPU), headline: the data-parallel TRAINING step of configs[2]
+  -- batch 6 per GPU, weighted cross-entropy, Adam, gradient all-reduce over RCCL inside the timed region ("weak"
+  scaling: per-GPU work fixed).  "inference" then holds the inference leg (independent shards per rank: the path has
+  no exchange step), "world_size" what the process group reports, and "allreduce" the time of each gradient bucket's
+  all-reduce alone.
+`--mode train` / `--mode infer` force one leg as the headline at any N.  Rank 0 prints exactly one JSON line.
 """
 from __future__ import annotations
 
@@ -54,6 +57,9 @@ def parse():
     ap.add_argument("--train-batch", type=int, default=6)
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--train-warmup", type=int, default=5)
+    ap.add_argument("--infer-steps", type=int, default=30, help="N > 1: steps of the inference leg reported beside the training headline")
+    ap.add_argument("--infer-warmup", type=int, default=5)
+    ap.add_argument("--no-fp32", action="store_true", help="auto mode at N = 1: skip the fp32 legs")
     return ap.parse_args()
 
 
@@ -133,13 +139,14 @@ def cpu_baseline(height, width, budget_s=20.0):
 
 
 def measured_traffic(kernel_prefix, pixels):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, mean over the kernel's
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, mean over the kernel's
     variants); only quoted when this run has the shape the counters were collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path) or pixels != 16 * 128 * 256:
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not paths or pixels != 16 * 128 * 256:
         return None
-    vals = [v for k, v in json.load(open(path)).items() if kernel_prefix in k]
+    vals = [v for k, v in json.load(open(paths[-1])).items() if kernel_prefix in k]
     return sum(vals) / len(vals) if vals else None
 
 
@@ -208,17 +215,32 @@ def roofline_infer(model, x, dtype_name):
     avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * len(plan))
     if dtype_name == "bf16":
         achieved = bytes_per_launch / avg_s / 1e9
-        return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": achieved / PEAK_HBM_GBS, "traffic": measured_traffic("conv1d_pair_kernel<64,", n * hh * ww), "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
-                "bytes_per_launch": bytes_per_launch, "flop_per_launch": flop, "mfma_tflops": flop / avg_s / 1e12}
+        traffic = measured_traffic("conv1d_pair_kernel<64,", n * hh * ww)
+        per_launch = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
+                      "bytes_per_launch": bytes_per_launch, "flop_per_launch": flop, "mfma_tflops": flop / avg_s / 1e12}
+        # The same time priced per BLOCK: a non_bottleneck_1d block needs x in and y out once (2 tensors); its two launches
+        # move 5 (x, mid | mid, x again, y).  achieved = algorithmic block bytes / time of the block's two launches.
+        block_s = 2 * avg_s
+        block_alg = 2.0 * tensor_bytes
+        per_block = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "achieved": block_alg / block_s / 1e9,
+                     "frac": block_alg / block_s / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_block": block_alg,
+                     "launch_bytes_per_block": 5.0 * tensor_bytes, "traffic": None if traffic is None else 2 * traffic,
+                     "avg_block_us": block_s * 1e6, "blocks_per_step": len(plan) // 2,
+                     "what": "64-channel non_bottleneck_1d block = two conv1d_pair launches; model: x read once, y written once"}
+        return per_launch, per_block
     achieved = flop / avg_s / 1e12
     return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
-            "flop_per_launch": flop}
+            "flop_per_launch": flop}, None
 
 
-def run_infer(args, world, rank, dev):
+def run_infer(args, world, rank, dev, dtype=None, steps=None, warmup=None, roofline=True):
     from erfnet_pytorch_amd.iouEval import iouEval
+    args = argparse.Namespace(**vars(args))
+    args.dtype = dtype or args.dtype
+    args.steps = steps or args.steps
+    args.warmup = args.warmup if warmup is None else warmup
     batch = args.batch or 16
     model = build_model(dev, args.dtype, args.classes)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -264,8 +286,10 @@ def run_infer(args, world, rank, dev):
     if rank == 0:
         flops = FWD_FLOP_PER_IMG * (args.height * args.width) / (512 * 1024)
         res["model_tflops"] = res["value"] * flops / 1e12
-        if not args.no_roofline:
-            res["roofline"] = roofline_infer(model, x, args.dtype)
+        if roofline and not args.no_roofline:
+            res["roofline"], per_block = roofline_infer(model, x, args.dtype)
+            if per_block is not None:
+                res["roofline_block"] = per_block
     return res
 
 
@@ -308,9 +332,27 @@ def run_multi(args, world, rank, dev):
             "config": {"workload": f"Multi_models(14) eval, batch {batch}/GPU, 3x{args.height}x{args.width}", "hip_graph": graph is not None}}
 
 
-def run_train(args, world, rank, dev):
+def run_train(args, world, rank, dev, dtype=None, steps=None, warmup=None, batch=None):
     from erfnet_pytorch_amd import trainer
+    args = argparse.Namespace(**vars(args))
+    args.dtype = dtype or args.dtype
+    args.steps = steps or args.steps
+    args.warmup = args.warmup if warmup is None else warmup
+    args.batch = batch if batch is not None else args.batch
     return trainer.bench_train(args, world, rank, dev, barrier, max_over_ranks)
+
+
+LEG_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "model_tflops")
+
+
+def leg(res):
+    return {k: res[k] for k in LEG_KEYS if k in res}
+
+
+def free_gpu():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def main():
@@ -319,9 +361,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and the package has no CPU path")
     world, rank, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
-    # auto: the headline value is the inference pipeline at every N (independent shards per rank, no
-    # data-path collective), and the data-parallel training step is measured in the same run and
-    # reported under "training" (its own steps/warmup, RCCL gradient all-reduce inside the timed region).
     if args.mode == "imagenet":
         from erfnet_pytorch_amd import trainer
         res = trainer.bench_imagenet(args, world, rank, dev, barrier, max_over_ranks)
@@ -329,13 +368,29 @@ def main():
         res = run_multi(args, world, rank, dev)
     elif args.mode == "train":
         res = run_train(args, world, rank, dev)
-    else:
+    elif args.mode == "infer":
         res = run_infer(args, world, rank, dev)
-        if args.mode == "auto" and not args.no_train:
-            targs = argparse.Namespace(**vars(args))
-            targs.batch, targs.steps, targs.warmup = args.train_batch, args.train_steps, args.train_warmup
-            tr = run_train(targs, world, rank, dev)
-            res["training"] = {k: tr[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "model_tflops")}
+    elif world == 1:
+        # auto, one GPU: inference is the headline; training, and both legs in fp32, ride in the same line
+        res = run_infer(args, world, rank, dev)
+        free_gpu()
+        if not args.no_train:
+            res["training"] = leg(run_train(args, world, rank, dev, steps=args.train_steps, warmup=args.train_warmup, batch=args.train_batch))
+            free_gpu()
+        if not args.no_fp32:
+            fp32 = {"inference": leg(run_infer(args, world, rank, dev, dtype="fp32", steps=10, warmup=3, roofline=False))}
+            free_gpu()
+            if not args.no_train:
+                fp32["training"] = leg(run_train(args, world, rank, dev, dtype="fp32", steps=8, warmup=2, batch=args.train_batch))
+                free_gpu()
+            res["fp32"] = fp32
+    else:
+        # auto, several GPUs: the data-parallel training step is the headline (the leg with an exchange step); the inference
+        # pipeline (independent shards) is reported beside it
+        res = run_train(args, world, rank, dev, batch=args.train_batch)
+        free_gpu()
+        res["inference"] = leg(run_infer(args, world, rank, dev, steps=args.infer_steps, warmup=args.infer_warmup, roofline=False))
+    res.setdefault("world_size", world)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.mode != "multi":
             res["cpu_baseline"] = cpu_baseline(args.height, args.width)

@@ -159,6 +159,29 @@ class Trainer:
             w.wait()
         self._pending = []
 
+    def time_buckets(self, reps=5, barrier=lambda: None, reduce_max=lambda v: v):
+        """Each gradient bucket's all-reduce ALONE (nothing to overlap with), mean of `reps` after one warm-up, slowest rank:
+        what the collective costs when it is fully exposed.  Sums garbage into the gradient arena: call between steps."""
+        import torch.distributed as dist
+        n = dist.get_world_size(self.group)
+        out = []
+        for lo, hi in self.buckets:
+            buf = self.gflat[lo:hi]
+            dist.all_reduce(buf, group=self.group)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dist.all_reduce(buf, group=self.group)
+            torch.cuda.synchronize()
+            ms = reduce_max((time.perf_counter() - t0) * 1e3 / reps)
+            nbytes = (hi - lo) * 4
+            out.append({"elements": hi - lo, "bytes": nbytes, "ms": ms, "algbw_GBs": nbytes / ms / 1e6,
+                        "busbw_GBs": nbytes / ms / 1e6 * 2 * (n - 1) / n})
+        self.gflat.zero_()
+        return {"buckets": out, "order": "backward completion: decoder, 128-channel encoder stage, the rest",
+                "overlapped_with_backward": self.overlap, "ranks": n}
+
     # -- one optimisation step ----------------------------------------------------------------
     def set_epoch(self, epoch, num_epochs, base_lr=5e-4):
         self.lr = poly_lr(base_lr, epoch, num_epochs)
@@ -355,7 +378,11 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
     flop_img = 2 * (3 * 26_612_727_808 - 46_006_272) * (args.height * args.width) / (512 * 1024)
     value = world * batch * args.steps / elapsed
+    extra = {"world_size": dist.get_world_size(group) if world > 1 else 1}
+    if tr.collective:
+        extra["allreduce"] = tr.time_buckets(barrier=lambda: barrier(world), reduce_max=lambda v: max_over_ranks(v, world, dev))
     return {
+        **extra,
         "metric": "img/s ERFNet 512x1024: bf16 inference (1 GPU) + training (1/2/4/8 MI355X)",
         "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
