@@ -100,6 +100,9 @@ SIGNATURES = {
     "erf_weighted_ce_fwd": (I, [P, I, P, P, I, I, LL, P, P, P]),
     "erf_weighted_ce_bwd": (I, [P, I, P, P, I, I, LL, P, P, P]),
     "erf_adam_fused_arena": (I, [P, P, P, P, LL, D, D, D, D, D, I, D, P]),
+    "erf_adam_advance": (I, [P, P, P, D, D, P]),
+    "erf_adam_fused_arena_hyper": (I, [P, P, P, P, LL, P, D, D, D, D, D, P]),
+    "erf_dropout2d_mask_many_counter": (I, [P, I, P, P, P, P]),
     "erf_sgd_fused_arena": (I, [P, P, P, LL, D, D, D, I, D, P]),
     "erf_conv1d_dgrad": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "erf_downsampler_dgrad_packed_bytes": (c_size_t, [I, I, I]),

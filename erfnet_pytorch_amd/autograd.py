@@ -346,19 +346,32 @@ def _next_seed():
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _mask_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
-def prepare_dropout_masks(mods, n, dev):
+def new_seed_state(dev):
+    """Device-resident seed state for prepare_dropout_masks(state=...): [base, masks drawn so far] as int64 bit patterns.
+    The base follows torch's seed like the host-side generator of dropout_mask()."""
+    base = (torch.initial_seed() * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    signed = base - (1 << 64) if base >= (1 << 63) else base
+    return torch.tensor([signed, 0], dtype=torch.int64, device=dev)
+
+
+def prepare_dropout_masks(mods, n, dev, state=None):
     """The masks of a forward pass for `mods` (the non_bottleneck_1d blocks with p > 0, in forward order) by ONE launch.
     Each block finds its mask in `_erf_mask_next` and uses it once; seeds advance exactly as if the blocks had drawn their
-    masks one by one, so the values are the same either way."""
+    masks one by one, so the values are the same either way.
+    `state` (new_seed_state): the seeds are derived on the device from a counter that lives there and moves on with every
+    call -- nothing in the launch changes from step to step on the host, which is what a captured graph needs."""
     import numpy as np
     todo = [m for m in mods if m.__dict__.get("_erf_forced_mask") is None]
     if not todo or len(todo) > 32:
         return
     counts = np.array([n * m.conv3x1_1.out_channels for m in todo], dtype=np.int32)
     ps = np.array([m.dropout.p for m in todo], dtype=np.float32)
-    seeds = np.array([_next_seed() for _ in todo], dtype=np.uint64)
     buf = torch.empty(int(counts.sum()), device=dev)
-    call("erf_dropout2d_mask_many", buf.data_ptr(), len(todo), counts.ctypes.data, ps.ctypes.data, seeds.ctypes.data, _stream())
+    if state is not None:
+        call("erf_dropout2d_mask_many_counter", buf.data_ptr(), len(todo), counts.ctypes.data, ps.ctypes.data, state.data_ptr(), _stream())
+    else:
+        seeds = np.array([_next_seed() for _ in todo], dtype=np.uint64)
+        call("erf_dropout2d_mask_many", buf.data_ptr(), len(todo), counts.ctypes.data, ps.ctypes.data, seeds.ctypes.data, _stream())
     off = 0
     for m, cnt in zip(todo, counts.tolist()):
         m.__dict__["_erf_mask_next"] = (buf[off:off + cnt].view(n, -1), n)

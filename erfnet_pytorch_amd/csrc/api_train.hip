@@ -182,6 +182,12 @@ int erf_dropout2d_mask_many(float* mask, int segments, const int* counts, const 
     return dropout_mask_many_launch(mask, segments, counts, p, seeds, (hipStream_t)stream);
 }
 
+int erf_dropout2d_mask_many_counter(float* mask, int segments, const int* counts, const float* p, unsigned long long* state,
+                                    void* stream) {
+    if (!mask || !counts || !p || !state) return ERF_EINVAL;
+    return dropout_mask_many_counter_launch(mask, segments, counts, p, state, (hipStream_t)stream);
+}
+
 int erf_maxpool2x2_backward(const void* x, const void* dz, void* dx, int dtype, int N, int Hin, int Win, int Cin, int ldz,
                             int zoff, int accumulate, void* stream) {
     if (!x || !dz || !dx || !dtype_ok(dtype) || N <= 0) return ERF_EINVAL;
@@ -230,6 +236,18 @@ int erf_adam_fused_arena(float* params, const float* grads, float* exp_avg, floa
     if (!params || !grads || !exp_avg || !exp_avg_sq) return ERF_EINVAL;
     return adam_launch(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                        (hipStream_t)stream);
+}
+
+int erf_adam_advance(int* step, const double* lr, float* hyper, double beta1, double beta2, void* stream) {
+    if (!step || !lr || !hyper) return ERF_EINVAL;
+    return adam_advance_launch(step, lr, hyper, beta1, beta2, (hipStream_t)stream);
+}
+
+int erf_adam_fused_arena_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* hyper,
+                               double beta1, double beta2, double eps, double weight_decay, double grad_scale, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !hyper) return ERF_EINVAL;
+    return adam_hyper_launch(params, grads, exp_avg, exp_avg_sq, n, hyper, beta1, beta2, eps, weight_decay, grad_scale,
+                             (hipStream_t)stream);
 }
 
 int erf_sgd_fused_arena(float* params, const float* grads, float* momentum_buf, long long n, double lr, double momentum,

@@ -39,6 +39,11 @@ int ce_fwd_launch(const void* z, int dtype, const long long* target, const float
                   float* partials, float* out, hipStream_t stream);
 int ce_bwd_launch(const void* z, int dtype, const long long* target, const float* weight, int N, int C, long long HW,
                   const float* coef, void* dz, hipStream_t stream);
+int dropout_mask_many_counter_launch(float* mask, int segments, const int* counts, const float* p, unsigned long long* state,
+                                     hipStream_t stream);
+int adam_advance_launch(int* step, const double* lr, float* hyper, double b1, double b2, hipStream_t stream);
+int adam_hyper_launch(float* p, const float* g, float* m, float* v, long long n, const float* hyper, double b1, double b2,
+                      double eps, double wd, double gscale, hipStream_t stream);
 int adam_launch(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,
                 double wd, int step, double gscale, hipStream_t stream);
 int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, double momentum, double wd, int first,

@@ -547,6 +547,47 @@ int dropout_mask_many_launch(float* mask, int segments, const int* counts, const
     return erf_check_launch();
 }
 
+// The same masks with the seeds kept on the device (state[0] = base, state[1] = number of masks drawn so far): segment s
+// uses seed = base + (state[1] + s + 1) * K, then the count moves on by the number of segments.  Nothing in the launch
+// depends on host values that change from step to step, so a captured graph can replay it.
+struct DropoutTableC { int n; int begin[ERF_DROPOUT_MAX + 1]; float p[ERF_DROPOUT_MAX]; };
+
+__global__ void dropout_mask_many_counter_kernel(float* __restrict__ mask, const DropoutTableC t,
+                                                 const unsigned long long* __restrict__ state) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.begin[t.n]) return;
+    int s = 0;
+    while (s + 1 < t.n && i >= t.begin[s + 1]) ++s;
+    const float p = t.p[s];
+    const unsigned long long seed = state[0] + (state[1] + (unsigned long long)(s + 1)) * 0xD1B54A32D192ED03ULL;
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i - t.begin[s] + 1);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    const float u = (float)(x >> 40) * (1.0f / 16777216.0f);
+    mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+__global__ void counter_add_kernel(unsigned long long* state, unsigned long long v) { state[1] += v; }
+
+int dropout_mask_many_counter_launch(float* mask, int segments, const int* counts, const float* p, unsigned long long* state,
+                                     hipStream_t stream) {
+    if (segments < 1 || segments > ERF_DROPOUT_MAX) return ERF_EINVAL;
+    DropoutTableC t{};
+    t.n = segments;
+    long long total = 0;
+    for (int s = 0; s < segments; ++s) {
+        if (counts[s] <= 0 || p[s] < 0.f || p[s] >= 1.f) return ERF_EINVAL;
+        t.begin[s] = (int)total; t.p[s] = p[s];
+        total += counts[s];
+        if (total > 0x7FFFFFFF) return ERF_EINVAL;
+    }
+    t.begin[segments] = (int)total;
+    hipLaunchKernelGGL(dropout_mask_many_counter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mask, t, state);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, stream, state, (unsigned long long)segments);
+    return erf_check_launch();
+}
+
 int dropout_mask_launch(float* mask, int count, float p, unsigned long long seed, hipStream_t stream) {
     if (count <= 0 || p < 0.f || p >= 1.f) return ERF_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, mask, count, p, seed);
@@ -771,6 +812,44 @@ int adam_launch(float* p, const float* g, float* m, float* v, long long n, doubl
     const double bc2s = sqrt(1.0 - pow(b2, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, n, (float)(lr / bc1), (float)b1,
                        (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, (float)bc2s, (float)gscale);
+    return erf_check_launch();
+}
+
+// Adam with the step count and the learning rate in device memory.  adam_advance_kernel (one thread) moves the count on and
+// leaves the two step-dependent factors in hyper[0..1]; adam_hyper_kernel reads them.  The arithmetic per element is
+// adam_kernel's.
+__global__ void adam_advance_kernel(int* step, const double* lr, float* hyper, double b1, double b2) {
+    const int s = *step + 1;
+    *step = s;
+    hyper[0] = (float)(*lr / (1.0 - pow(b1, (double)s)));
+    hyper[1] = (float)sqrt(1.0 - pow(b2, (double)s));
+}
+
+__global__ __launch_bounds__(256) void adam_hyper_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long long n, const float* __restrict__ hyper, float b1,
+                                                         float omb1, float b2, float omb2, float eps, float wd, float gscale) {
+    const float step_size = hyper[0], bc2_sqrt = hyper[1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+int adam_advance_launch(int* step, const double* lr, float* hyper, double b1, double b2, hipStream_t stream) {
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, stream, step, lr, hyper, b1, b2);
+    return erf_check_launch();
+}
+
+int adam_hyper_launch(float* p, const float* g, float* m, float* v, long long n, const float* hyper, double b1, double b2,
+                      double eps, double wd, double gscale, hipStream_t stream) {
+    if (n <= 0) return ERF_EINVAL;
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, m, v, n, hyper, (float)b1, (float)(1.0 - b1),
+                       (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, (float)gscale);
     return erf_check_launch();
 }
 

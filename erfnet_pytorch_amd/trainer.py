@@ -59,11 +59,11 @@ def _flush_batch_counters(pending):
         pending.clear()
 
 
-def _prepare_masks(model, images):
+def _prepare_masks(model, images, state=None):
     """All Dropout2d masks of the coming forward pass by one launch (the blocks with p > 0, in forward order)."""
     if model.training:
         mods = [m for m in model.modules() if isinstance(m, E.non_bottleneck_1d) and m.dropout.p != 0]
-        ag.prepare_dropout_masks(mods, images.shape[0], images.device)
+        ag.prepare_dropout_masks(mods, images.shape[0], images.device, state)
 
 
 def _refresh_bank(bank, model, images):
@@ -79,12 +79,17 @@ def _refresh_bank(bank, model, images):
 
 class Trainer:
     def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
-                 group=None, world_size=1, overlap=True, only_encode=False, fused_head_loss=True, force_collectives=False):
+                 group=None, world_size=1, overlap=True, only_encode=False, fused_head_loss=True, force_collectives=False,
+                 graph=False):
         """`only_encode`: the first stage of the reference's recipe (train/main.py:495 `train(args, model, True)`,
         :203 `model(inputs, only_encode=enc)`): logits from Encoder.output_conv at 1/8 resolution against targets of
         that size; the decoder's parameters take no part and are left untouched.
         `force_collectives`: issue the loss and gradient-bucket all-reduces even when world_size is 1 (a one-rank process
-        group exercises the whole collective path -- hooks, side-stream ordering, waits -- on a single GPU)."""
+        group exercises the whole collective path -- hooks, side-stream ordering, waits -- on a single GPU).
+        `graph`: step() captures the whole optimisation step (zero_grad .. Adam, collectives included) into a HIP graph
+        the second time it sees an input shape and replays it from then on; the inputs are copied into the graph's
+        static buffers.  Everything that changes from step to step lives on the device for this (dropout seed counter,
+        Adam's step count and learning rate), graph or not, so both ways of running give the same bits."""
         self.model = model
         self.only_encode = only_encode
         # Decoder.output_conv + loss in one pass each way (the logits stay in registers); step() then returns
@@ -92,7 +97,8 @@ class Trainer:
         self.fused_head_loss = fused_head_loss and not only_encode
         self.group, self.world = group, world_size
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
-        self.step_count = 0
+        self._step_dev = None
+        self._step_host = 0
         self.collective = world_size > 1 or (force_collectives and group is not None)
         self.overlap = overlap and self.collective
         dev = next(model.parameters()).device
@@ -131,6 +137,15 @@ class Trainer:
             mod.__dict__["_erf_grad_sink_zeroed"] = True    # step() clears the arena before every backward pass
             mod.__dict__["_erf_grad_sink_epoch"] = self._epoch
 
+        # per-step scalars on the device: a captured step must not depend on host values that change
+        self._seed_state = ag.new_seed_state(dev)
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float64, device=dev)
+        self._lr_on_dev = float(lr)
+        self._hyper = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.use_graph = bool(graph)
+        self._graphs = {}                               # input signature -> (graph, static images, static targets, loss, outputs)
+        self._seen = set()
         self._bank = None                               # packed factorized-conv weights, refreshed once per step
         self._counted = _take_over_batch_counters(model)
         # all-reduce buckets (backward-completion order) and the ranges Adam may touch
@@ -142,6 +157,22 @@ class Trainer:
                 model.decoder.layers[0].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(0)
             model.encoder.layers[6].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(last - 1)
             model.encoder.initial_block.__dict__["_erf_after_backward"] = lambda: self._launch_bucket(last)
+
+    # -- Adam's step count: the device copy is what the kernels read, the host copy mirrors it --------
+    @property
+    def step_count(self):
+        return self._step_host
+
+    @step_count.setter
+    def step_count(self, value):
+        self._step_host = int(value)
+        if getattr(self, "_step_dev", None) is not None:
+            self._step_dev.fill_(int(value))
+
+    def _sync_lr(self):
+        if self.lr != self._lr_on_dev:                                # set_epoch() / a resumed optimiser changed it
+            self._lr_dev.fill_(float(self.lr))
+            self._lr_on_dev = float(self.lr)
 
     # -- collectives ------------------------------------------------------------------------
     def _launch_bucket(self, i):
@@ -191,12 +222,58 @@ class Trainer:
         self.gflat.zero_()
 
     def step(self, images, targets):
-        """images [N,3,H,W]; targets [N,1,H,W] or [N,H,W] int64.  Returns the (global) loss tensor."""
+        """images [N,3,H,W]; targets [N,1,H,W] or [N,H,W] int64.  Returns (global loss tensor, logits or None)."""
         if targets.dim() == 4:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
+        self._sync_lr()
+        if not self.use_graph or self._host_masks():
+            return self._step_eager(images, targets)
+        key = (tuple(images.shape), images.dtype, tuple(targets.shape), getattr(self.model, "compute_dtype", None))
+        entry = self._graphs.get(key)
+        if entry is None:
+            if key not in self._seen:                                 # first sight of a shape: run it eagerly (sizes caches, workspaces)
+                self._seen.add(key)
+                return self._step_eager(images, targets)
+            entry = self._capture(key, images, targets)
+        graph, gx, gt, loss, outputs = entry
+        gx.copy_(images)
+        gt.copy_(targets)
+        graph.replay()
+        self._after_replayed_step()
+        return loss, outputs
+
+    def _host_masks(self):
+        """Forced dropout masks (a test hook) that live in host memory would be uploaded inside the step: not capturable."""
+        for m in self.model.modules():
+            f = m.__dict__.get("_erf_forced_mask")
+            if f is not None and (f.device != self.dev or f.dtype != torch.float32):
+                return True
+        return False
+
+    def _capture(self, key, images, targets):
+        gx, gt = images.clone(), targets.clone()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        # everything the step changed on the HOST during capture is undone below: the capture launches nothing
+        host = (self._step_host, self._epoch[0])
+        with torch.cuda.graph(graph):
+            loss, outputs = self._step_eager(gx, gt)
+        self._step_host, self._epoch[0] = host
+        entry = (graph, gx, gt, loss, outputs)
+        self._graphs[key] = entry
+        return entry
+
+    def _after_replayed_step(self):
+        """Host-side mirrors of what a replayed step changed on the device."""
+        from . import ops
+        self._epoch[0] += 1
+        self._step_host += 1
+        ops.bump_param_epoch()
+
+    def _step_eager(self, images, targets):
         self.zero_grad()                                              # optimizer.zero_grad(), train/main.py:200
         self._refresh_packed(images)
-        _prepare_masks(self.model, images)
+        _prepare_masks(self.model, images, self._seed_state)
         group = self.group if self.collective else None
         if self.fused_head_loss:
             from . import ops
@@ -268,12 +345,17 @@ class Trainer:
     def optimizer_step(self):
         from . import ops
         ops.bump_param_epoch()                          # parameters change below through raw pointers
-        self.step_count += 1
+        self._sync_lr()
+        self._step_host += 1
         st = ops._stream()
+        # the step count and the learning rate are read from device memory (see __init__): count += 1, then the two
+        # step-dependent factors, then the update of every active range
+        call("erf_adam_advance", self._step_dev.data_ptr(), self._lr_dev.data_ptr(), self._hyper.data_ptr(),
+             float(self.betas[0]), float(self.betas[1]), st)
         for lo, hi in self.active:
-            call("erf_adam_fused_arena", self.flat[lo:hi].data_ptr(), self.gflat[lo:hi].data_ptr(),
-                 self.exp_avg[lo:hi].data_ptr(), self.exp_avg_sq[lo:hi].data_ptr(), hi - lo, float(self.lr),
-                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_count, 1.0, st)
+            call("erf_adam_fused_arena_hyper", self.flat[lo:hi].data_ptr(), self.gflat[lo:hi].data_ptr(),
+                 self.exp_avg[lo:hi].data_ptr(), self.exp_avg_sq[lo:hi].data_ptr(), hi - lo, self._hyper.data_ptr(),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), 1.0, st)
 
 
 class ArenaSGD:
@@ -356,7 +438,7 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else None
     group = dist.group.WORLD if world > 1 else None
-    tr = Trainer(model, CITYSCAPES_WEIGHTS, group=group, world_size=world)
+    tr = Trainer(model, CITYSCAPES_WEIGHTS, group=group, world_size=world, graph=not getattr(args, "no_graph", False))
     torch.manual_seed(1234 + rank)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(batch, 3, args.height, args.width, device=dev, generator=gen)
@@ -366,7 +448,7 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     def step():
         return tr.step(x, t)                  # zero_grad + forward + loss + backward + all-reduce + Adam
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 3)):        # the first step sizes caches, the second is captured, replays from the third
         loss, _ = step()
     torch.cuda.synchronize()
     barrier(world)
@@ -389,7 +471,7 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"ERFNet(20) training step (fwd + weighted CE + bwd + RCCL grad all-reduce + Adam), batch {batch}/GPU, "
                                f"3x{args.height}x{args.width}, data parallel x{world}",
-                   "global_batch": batch * world, "final_loss": float(loss)},
+                   "global_batch": batch * world, "final_loss": float(loss), "hip_graph": bool(tr._graphs)},
         "model_tflops": value * flop_img / 1e12,
     }
 

@@ -187,6 +187,11 @@ int erf_dropout2d_mask(float* mask, int count, float p, unsigned long long seed,
  * seeds are host arrays. */
 int erf_dropout2d_mask_many(float* mask, int segments, const int* counts, const float* p, const unsigned long long* seeds,
                             void* stream);
+/* The same masks with the seeds kept in device memory, for steps replayed from a captured graph: state[0] = base,
+ * state[1] = masks drawn so far; segment s gets seed = state[0] + (state[1] + s + 1) * 0xD1B54A32D192ED03 (mod 2^64) and
+ * state[1] then advances by `segments` (a second, one-thread launch).  counts / p are host arrays. */
+int erf_dropout2d_mask_many_counter(float* mask, int segments, const int* counts, const float* p, unsigned long long* state,
+                                    void* stream);
 /* MaxPool2d(2, stride 2) backward of the DownsamplerBlock (train/erfnet.py:16,20): routes
  * dz[..., zoff:zoff+Cin] (channel stride ldz) to the first maximum of each window of x;
  * accumulate != 0 adds to dx (after the conv part's data gradient), else overwrites. */
@@ -212,6 +217,12 @@ int erf_weighted_ce_bwd(const void* logits, int dtype, const long long* target, 
  * doubles (as Python floats are): 1 - beta and the bias corrections are formed in double first. */
 int erf_adam_fused_arena(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, double lr,
                          double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
+/* Adam with its step count and learning rate in device memory (a captured graph replays the step without host values):
+ * erf_adam_advance: *step += 1; hyper[0] = lr / (1 - beta1^step), hyper[1] = sqrt(1 - beta2^step), formed in double.
+ * erf_adam_fused_arena_hyper: erf_adam_fused_arena's update with those two factors read from hyper. */
+int erf_adam_advance(int* step, const double* lr, float* hyper, double beta1, double beta2, void* stream);
+int erf_adam_fused_arena_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* hyper,
+                               double beta1, double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 int erf_sgd_fused_arena(float* params, const float* grads, float* momentum_buf, long long n, double lr, double momentum,
                         double weight_decay, int first_step, double grad_scale, void* stream);
 

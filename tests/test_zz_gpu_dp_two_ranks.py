@@ -29,7 +29,7 @@ def _build(dtype):
     m.compute_dtype = torch.bfloat16 if dtype == "bf16" else None
     for mod in m.modules():
         if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
-            mod.__dict__["_erf_forced_mask"] = torch.ones(NB, mod.conv3x1_1.out_channels)       # dropout off: deterministic
+            mod.__dict__["_erf_forced_mask"] = torch.ones(NB, mod.conv3x1_1.out_channels, device="cuda:0")   # dropout off: deterministic
     return m
 
 
@@ -122,7 +122,11 @@ def test_two_rank_trainer_step_equals_dataparallel_semantics(dtype, overlap, tol
         assert err <= tol, (k, err)
 
 
-def _rccl_worker(rank, world, store_file, dtype, overlap, q):
+def _rccl_graph_worker(rank, world, store_file, dtype, overlap, q):
+    _rccl_worker(rank, world, store_file, dtype, overlap, q, graph=True, steps=4)
+
+
+def _rccl_worker(rank, world, store_file, dtype, overlap, q, graph=False, steps=2):
     """One rank, backend nccl (= RCCL): the production collective path on a single GPU."""
     import torch.distributed as dist
     from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
@@ -133,13 +137,15 @@ def _rccl_worker(rank, world, store_file, dtype, overlap, q):
         x, t = _shard(0)
         res = []
         for group in (dist.group.WORLD, None):
-            tr = Trainer(_build(dtype), CITYSCAPES_WEIGHTS, group=group, world_size=1, overlap=overlap, force_collectives=True)
+            tr = Trainer(_build(dtype), CITYSCAPES_WEIGHTS, group=group, world_size=1, overlap=overlap, force_collectives=True,
+                         graph=graph and group is not None)
             assert tr.collective == (group is not None) and tr.overlap == (overlap and group is not None)
             losses = []
-            for _ in range(2):
+            for _ in range(steps):
                 loss, _ = tr.step(x, t)
                 losses.append(float(loss))
             torch.cuda.synchronize()
+            assert bool(tr._graphs) == (graph and group is not None)
             res.append((losses, tr.gflat.cpu().numpy().copy(), tr.flat.cpu().numpy().copy()))
         q.put((0, res))
         dist.barrier()
@@ -153,6 +159,17 @@ def test_collective_path_on_rccl_with_one_rank_is_bit_identical_to_no_group(dtyp
     thread behind the kernels of the raw current stream, the 2-float loss all-reduce, Work.wait() before Adam) on RCCL with a
     one-rank group: sums over one rank change nothing, so two optimisation steps must match the group-less run bit for bit."""
     got = _run(1, dtype, overlap, tmp_path, worker=_rccl_worker)
+    (l_a, g_a, p_a), (l_b, g_b, p_b) = got[0][0]
+    assert l_a == l_b
+    assert np.array_equal(g_a, g_b) and np.array_equal(p_a, p_b)
+
+
+@pytest.mark.parametrize("dtype,overlap", [("bf16", True), ("bf16", False)])
+def test_captured_step_with_rccl_collectives_is_bit_identical_to_the_launched_one(dtype, overlap, tmp_path):
+    """Trainer(graph=True) over a one-rank RCCL group: the loss all-reduce and the three asynchronous gradient-bucket
+    all-reduces are captured into the HIP graph with the kernels; four steps (two of them replays) must match the
+    group-less, kernel-by-kernel run bit for bit."""
+    got = _run(1, dtype, overlap, tmp_path, worker=_rccl_graph_worker)
     (l_a, g_a, p_a), (l_b, g_b, p_b) = got[0][0]
     assert l_a == l_b
     assert np.array_equal(g_a, g_b) and np.array_equal(p_a, p_b)
