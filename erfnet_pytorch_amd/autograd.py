@@ -227,11 +227,7 @@ def conv1d_dgrad_bn_backward(dy, packed_t, gate, residual, axis, dilation, z, me
 
 def bn_apply(z, center, scale, shift, residual=None, mask=None, relu=True):
     """y = act(((z - center) * scale + shift) * mask + residual)"""
-    n, h, w, c = z.shape
-    y = torch.empty_like(z)
-    call("erf_bn_apply", z.data_ptr(), y.data_ptr(), _p(center), scale.data_ptr(), shift.data_ptr(), _p(residual), _p(mask),
-         ops.dt(z), n, h * w, c, int(relu), _stream())
-    return y
+    return ops.T.bn_apply(z, center, scale, shift, residual, mask, relu)
 
 
 def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=False, dgamma=None, dbeta=None):
@@ -249,8 +245,9 @@ def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=F
 
 
 def channel_sum(z, out=None):
+    if out is None:
+        return ops.T.channel_sum(z)
     c = z.shape[-1]
-    out = torch.empty(c, device=z.device) if out is None else out
     ws = _ws(size_query("erf_bn_workspace_bytes", c), z.device)
     call("erf_channel_sum", z.data_ptr(), ops.dt(z), z.numel() // c, c, out.data_ptr(), ws.data_ptr(), _stream())
     return out
@@ -270,11 +267,7 @@ def pre_bn_bias_grad(dz, batch_stats, out=None, out_is_zero=False):
 
 
 def conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation):
-    n, h, w, c = dy.shape
-    dx = torch.empty_like(dy)
-    call("erf_conv1d_dgrad", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), _p(gate), _p(residual), ops.dt(dy), n, h, w,
-         c, axis, dilation, _stream())
-    return dx
+    return ops.T.conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation)
 
 
 def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None, defer=False):
@@ -290,7 +283,9 @@ def conv1d_wgrad(x, dz, wshape, axis, dilation, out=None, defer=False):
         with _PENDING_LOCK:
             _PENDING_WGRAD.setdefault(x.device.index, []).append((desc, 3 * c * c, ws, dw))
         return dw
-    dw = torch.empty(wshape, device=x.device) if out is None else out
+    if out is None:
+        return ops.T.conv1d_wgrad(x, dz, axis, dilation).view(wshape)
+    dw = out
     nb = size_query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
     ws = _ws(nb, x.device)
     call("erf_conv1d_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ops.dt(x), n, h, w, c, axis, dilation,
@@ -385,9 +380,7 @@ def dropout_mask(n, c, p, dev, forced=None, mod=None):
     if ready is not None and ready[1] == n and ready[0].shape[1] == c and ready[0].device == dev:
         return ready[0]
     seed = _next_seed()
-    mask = torch.empty(n * c, device=dev)
-    call("erf_dropout2d_mask", mask.data_ptr(), n * c, float(p), seed, _stream())
-    return mask.view(n, c)
+    return ops.T.dropout2d_mask(torch.empty(0, device=dev), n, c, float(p), seed - (1 << 64) if seed >= (1 << 63) else seed)
 
 
 class _Sink:

@@ -134,19 +134,16 @@ class non_bottleneck_1d(_Block):
     def forward_nhwc(self, x):
         c = self._cached(ops.dt(x))
         d = self.dilated
-        if FUSE_BLOCKS:
-            z = ops.nb1d_block(x, (c["w1"], c["w2"], c["w3"], c["w4"]), c["table"], d)
-            if z is not None:
-                return z
-        y = ops.conv1d_pair(x, c["w1"], c["t1"], c["w2"], c["s2"], c["t2"], None, 1) if FUSE_PAIRS else None
-        if y is None:
-            y = ops.conv1d(x, c["w1"], None, c["t1"], None, AXIS_H, 1, True)
-            y = ops.conv1d(y, c["w2"], c["s2"], c["t2"], None, AXIS_W, 1, True)
-        z = ops.conv1d_pair(y, c["w3"], c["t3"], c["w4"], c["s4"], c["t4"], x, d) if FUSE_PAIRS else None
-        if z is None:
-            z = ops.conv1d(y, c["w3"], None, c["t3"], None, AXIS_H, d, True)
-            z = ops.conv1d(z, c["w4"], c["s4"], c["t4"], x, AXIS_W, d, True)
-        return z
+        if FUSE_BLOCKS and d == 1 and x.dtype == torch.bfloat16 and self.chann == 64:
+            return ops.T.nb1d_block(x, c["w1"], c["w2"], c["w3"], c["w4"], c["table"], d)
+        if FUSE_PAIRS:
+            # one launch per conv3x1 -> conv1x3 pair where the library takes the shape, else two (decided inside the op)
+            y = ops.T.conv1d_pair(x, c["w1"], c["t1"], c["w2"], c["s2"], c["t2"], None, 1, True)
+            return ops.T.conv1d_pair(y, c["w3"], c["t3"], c["w4"], c["s4"], c["t4"], x, d, True)
+        y = ops.conv1d(x, c["w1"], None, c["t1"], None, AXIS_H, 1, True)
+        y = ops.conv1d(y, c["w2"], c["s2"], c["t2"], None, AXIS_W, 1, True)
+        z = ops.conv1d(y, c["w3"], None, c["t3"], None, AXIS_H, d, True)
+        return ops.conv1d(z, c["w4"], c["s4"], c["t4"], x, AXIS_W, d, True)
 
 
 class UpsamplerBlock(_Block):

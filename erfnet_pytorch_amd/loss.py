@@ -40,10 +40,7 @@ class _WeightedCE(torch.autograd.Function):
             raise ValueError(f"expected target of shape {(n, h, w)}, got {tuple(target.shape)}")
         dev = logits.device
         wt = None if weight is None else weight.detach().to(dev, torch.float32).contiguous()
-        out3 = torch.empty(3, device=dev)
-        ws = torch.empty(query("erf_ce_workspace_bytes"), dtype=torch.uint8, device=dev)
-        call("erf_weighted_ce_fwd", logits.data_ptr(), ops.dt(logits), target.data_ptr(), 0 if wt is None else wt.data_ptr(),
-             n, c, h * w, out3.data_ptr(), ws.data_ptr(), _stream())
+        out3 = ops.T.weighted_ce_fwd(logits, target, wt)
         num, den = global_weighted_mean(out3[0], out3[1], group)
         ctx.save_for_backward(logits, target, den.reshape(1))
         ctx.weight = wt
@@ -54,10 +51,7 @@ class _WeightedCE(torch.autograd.Function):
         logits, target, den = ctx.saved_tensors
         n, c, h, w = logits.shape
         coef = (gout.reshape(1).float() / den).contiguous()
-        dlogits = torch.empty_like(logits)
-        wt = ctx.weight
-        call("erf_weighted_ce_bwd", logits.data_ptr(), ops.dt(logits), target.data_ptr(), 0 if wt is None else wt.data_ptr(),
-             n, c, h * w, coef.data_ptr(), dlogits.data_ptr(), _stream())
+        dlogits = ops.T.weighted_ce_bwd(logits, target, ctx.weight, coef)
         return (dlogits[:, :, 0, 0] if ctx.flat else dlogits), None, None, None
 
 

@@ -11,7 +11,10 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from . import torch_ops  # noqa: F401  (registers torch.ops.erfnet_mi355.*)
 from ._lib import AXIS_H, AXIS_W, BF16, F32, call, query
+
+T = torch.ops.erfnet_mi355
 
 
 def _stream() -> int:
@@ -241,8 +244,10 @@ def pack_pointwise(w: torch.Tensor, code: int) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- forward ops (NHWC in, NHWC out)
 def conv1d(x, packed, scale, shift, residual, axis: int, dilation: int, relu: bool, out=None):
+    if out is None:
+        return T.conv1d(x, packed, scale, shift, residual, axis, dilation, relu)
     n, h, w, c = x.shape
-    y = torch.empty_like(x) if out is None else out
+    y = out
     call("erf_conv1d_factorized", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), _p(residual),
          dt(x), n, h, w, c, axis, dilation, int(relu), _stream())
     return y
@@ -264,7 +269,8 @@ def conv1d_pair(x, packed_a, shift_a, packed_b, scale_b, shift_b, residual, dila
 
 def nb1d_block(x, packed4, table, dilation: int, out=None):
     """A whole non_bottleneck_1d block (eval mode, BatchNorms folded) in one launch.  Returns None when the library does not
-    take the shape (the caller then issues the two conv1d_pair launches)."""
+    take the shape (the caller then issues the two conv1d_pair launches).  torch.ops.erfnet_mi355.nb1d_block is the same
+    launch as a registered op (it raises instead of returning None)."""
     n, h, w, c = x.shape
     y = torch.empty_like(x) if out is None else out
     rc = query("erf_nb1d_block_infer", x.data_ptr(), y.data_ptr(), packed4[0].data_ptr(), packed4[1].data_ptr(), packed4[2].data_ptr(),
@@ -277,8 +283,10 @@ def nb1d_block(x, packed4, table, dilation: int, out=None):
 
 
 def downsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None):
+    if out is None:
+        return T.downsampler(x, packed, scale, shift, cout, relu)
     n, h, w, cin = x.shape
-    y = torch.empty((n, h // 2, w // 2, cout), dtype=x.dtype, device=x.device) if out is None else out
+    y = out
     call("erf_downsampler", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), dt(x), n, h, w, cin, cout,
          int(relu), _stream())
     return y
@@ -288,15 +296,19 @@ def stem(x_nchw, w, scale, shift, code: int, relu: bool = True, out=None):
     n, c, h, w_ = x_nchw.shape
     if c != 3:
         raise ValueError("the initial block takes 3-channel images")
-    y = torch.empty((n, h // 2, w_ // 2, 16), dtype=tdtype(code), device=x_nchw.device) if out is None else out
+    if out is None:
+        return T.stem(x_nchw, w, scale, shift, code, relu)
+    y = out
     call("erf_stem_downsampler", x_nchw.data_ptr(), dt(x_nchw), y.data_ptr(), w.data_ptr(), _p(scale), _p(shift), code,
          n, h, w_, int(relu), _stream())
     return y
 
 
 def upsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None):
+    if out is None:
+        return T.upsampler(x, packed, scale, shift, cout, relu)
     n, h, w, cin = x.shape
-    y = torch.empty((n, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device) if out is None else out
+    y = out
     call("erf_upsampler_convT3x3s2", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), dt(x), n, h, w,
          cin, cout, int(relu), _stream())
     return y
@@ -305,6 +317,10 @@ def upsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None):
 def output_conv(x, packed, bias, nc: int, want_logits: bool = True, logits_f32: bool = True, want_labels: bool = False,
                 label_dtype=torch.int64, logits_out=None, labels_out=None):
     """Returns (logits NCHW or None, labels [N,2H,2W] or None)."""
+    if logits_out is None and labels_out is None and (want_logits or want_labels):
+        lo, la = T.output_conv(x, packed, bias, nc, want_logits, logits_f32,
+                               (1 if label_dtype == torch.uint8 else 8) if want_labels else 0)
+        return (lo if want_logits else None), (la if want_labels else None)
     n, h, w, cin = x.shape
     logits = labels = None
     if want_logits:
@@ -319,32 +335,18 @@ def output_conv(x, packed, bias, nc: int, want_logits: bool = True, logits_f32: 
 
 
 def pointwise(x, packed, bias, nc: int, out_f32: bool = True):
-    n, h, w, cin = x.shape
-    y = torch.empty((n, nc, h, w), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-    call("erf_pointwise_conv", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(bias), int(out_f32), dt(x), n, h, w, cin,
-         nc, _stream())
-    return y
+    return T.pointwise(x, packed, bias, nc, out_f32)
 
 
 # --------------------------------------------------------------------------- metrics
 def argmax_c(logits: torch.Tensor, label_dtype=torch.int64) -> torch.Tensor:
     """outputs.max(1)[1] on NCHW-contiguous logits -> [N,H,W]."""
-    logits = logits.contiguous()
-    n, c, h, w = logits.shape
-    lab = torch.empty((n, h, w), dtype=label_dtype, device=logits.device)
-    call("erf_argmax_c", logits.data_ptr(), dt(logits), lab.data_ptr(), lab.element_size(), n, c, h * w, _stream())
-    return lab
+    if label_dtype not in (torch.uint8, torch.int64):
+        raise TypeError("label maps are uint8 or int64")
+    return T.argmax_c(logits.contiguous(), 1 if label_dtype == torch.uint8 else 8)
 
 
 def iou_hist_accumulate(pred: torch.Tensor, label: torch.Tensor, nc: int, hist: torch.Tensor):
     """hist (int64 [nc*nc+1], device) += confusion counts of (label, pred)."""
-    pred = pred.contiguous()
-    label = label.contiguous()
-    if pred.numel() != label.numel():
-        raise ValueError("prediction and label maps differ in size")
-    for t in (pred, label):
-        if t.dtype not in (torch.uint8, torch.int64):
-            raise TypeError("label maps must be uint8 or int64")
-    call("erf_iou_hist_accumulate", pred.data_ptr(), pred.element_size(), label.data_ptr(), label.element_size(),
-         pred.numel(), nc, hist.data_ptr(), _stream())
+    T.iou_hist_accumulate(pred.contiguous(), label.contiguous(), nc, hist)
     return hist

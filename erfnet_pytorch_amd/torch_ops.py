@@ -1,0 +1,339 @@
+"""The engine's operators as PyTorch custom ops: namespace `erfnet_mi355`, registered with torch.library.
+
+    torch.ops.erfnet_mi355.<op>(...)
+
+Every op has
+  * a device kernel ("CUDA" dispatch key, which is what ROCm devices use): shape checks, output allocation from torch's
+    caching allocator, one call through the C ABI (include/erfnet_mi355.h) on the calling thread's current stream;
+  * a fake kernel (torch.library.register_fake): output shapes / dtypes / devices only, so FakeTensorMode, meta tensors and
+    torch.export's shape propagation see through the ops without touching a GPU.
+There is no CPU kernel on purpose: a CPU tensor raises NotImplementedError from the dispatcher.
+
+Activations are NHWC tensors [N,H,W,C] (fp32 or bf16, contiguous); `packed*` arguments are the weight images written by
+the erf_*_pack entry points (ops.pack_*).  The ops carry no autograd formulas: training goes through the autograd.Function
+classes of autograd.py, whose forward / backward bodies call these ops (and, for the pieces that hand workspaces and deferred
+reductions from one launch to the next, the C ABI directly).
+
+The nn.Module forwards (erfnet.py, multi_models.py, erfnet_imagenet.py), loss.py and iouEval.py reach the kernels through
+ops.py, whose functional entry points dispatch here; `out=` variants of ops.py write into caller-owned memory and call the
+C ABI directly.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import AXIS_H, AXIS_W, BF16, F32, call, query, size_query
+
+NS = "erfnet_mi355"
+LIB = torch.library.Library(NS, "DEF")
+OPS = []                      # names, in registration order (tests walk this list)
+
+
+def _stream() -> int:
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"erfnet_pytorch_amd computes in float32 or bfloat16, got {t.dtype}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _nhwc(t: torch.Tensor, what: str):
+    if t.dim() != 4 or not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous NHWC tensor [N,H,W,C], got shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def _label_dtype(nbytes: int) -> torch.dtype:
+    if nbytes == 1:
+        return torch.uint8
+    if nbytes == 8:
+        return torch.int64
+    raise ValueError("label maps are uint8 (1 byte) or int64 (8 bytes)")
+
+
+def _register(schema: str, impl, fake):
+    name = schema.split("(", 1)[0]
+    LIB.define(schema)
+    LIB.impl(name, impl, "CUDA")
+    torch.library.register_fake(f"{NS}::{name}", fake, lib=LIB)
+    OPS.append(name)
+
+
+# ------------------------------------------------------------------------------------------------ factorized convolutions
+def _conv1d(x, packed, scale, shift, residual, axis, dilation, relu):
+    _nhwc(x, "conv1d")
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    call("erf_conv1d_factorized", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), _p(residual),
+         _dt(x), n, h, w, c, axis, dilation, int(relu), _stream())
+    return y
+
+
+def _like_x(x, *a):
+    return torch.empty_like(x)
+
+
+_register("conv1d(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, Tensor? residual, int axis, int dilation, bool relu) -> Tensor",
+          _conv1d, _like_x)
+
+
+def _conv1d_pair(x, packed_a, shift_a, packed_b, scale_b, shift_b, residual, dilation, relu):
+    """conv3x1 -> +shift_a -> ReLU -> conv1x3 (dilated) -> scale_b / shift_b (+ residual) -> ReLU.  One launch where the
+    library takes the shape (bf16, the tile utilisation rule of erf_conv1d_pair), else the two single-convolution launches."""
+    _nhwc(x, "conv1d_pair")
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    rc = query("erf_conv1d_pair", x.data_ptr(), y.data_ptr(), packed_a.data_ptr(), packed_b.data_ptr(), 0, _p(shift_a),
+               _p(scale_b), _p(shift_b), _p(residual), _dt(x), n, h, w, c, dilation, int(relu), _stream())
+    if rc == 0:
+        return y
+    if rc != -2:
+        raise RuntimeError(f"erf_conv1d_pair failed with status {rc}")
+    mid = _conv1d(x, packed_a, None, shift_a, None, AXIS_H, dilation, True)
+    return _conv1d(mid, packed_b, scale_b, shift_b, residual, AXIS_W, dilation, relu)
+
+
+_register("conv1d_pair(Tensor x, Tensor packed_a, Tensor shift_a, Tensor packed_b, Tensor? scale_b, Tensor shift_b, Tensor? residual, "
+          "int dilation, bool relu) -> Tensor", _conv1d_pair, _like_x)
+
+
+def _nb1d_block(x, w1, w2, w3, w4, table, dilation):
+    _nhwc(x, "nb1d_block")
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    rc = query("erf_nb1d_block_infer", x.data_ptr(), y.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), w4.data_ptr(),
+               table.data_ptr(), _dt(x), n, h, w, c, dilation, _stream())
+    if rc == -2:
+        raise NotImplementedError("nb1d_block takes bf16, 64 channels, dilation 1 (erf_nb1d_block_infer); use conv1d_pair twice")
+    if rc != 0:
+        raise RuntimeError(f"erf_nb1d_block_infer failed with status {rc}")
+    return y
+
+
+_register("nb1d_block(Tensor x, Tensor w1, Tensor w2, Tensor w3, Tensor w4, Tensor table, int dilation) -> Tensor",
+          _nb1d_block, _like_x)
+
+
+def _conv1d_dgrad(dy, packed_t, gate, residual, axis, dilation):
+    _nhwc(dy, "conv1d_dgrad")
+    n, h, w, c = dy.shape
+    dx = torch.empty_like(dy)
+    call("erf_conv1d_dgrad", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), _p(gate), _p(residual), _dt(dy), n, h, w,
+         c, axis, dilation, _stream())
+    return dx
+
+
+_register("conv1d_dgrad(Tensor dy, Tensor packed_t, Tensor? gate, Tensor? residual, int axis, int dilation) -> Tensor",
+          _conv1d_dgrad, _like_x)
+
+
+def _conv1d_wgrad(x, dz, axis, dilation):
+    _nhwc(x, "conv1d_wgrad")
+    n, h, w, c = x.shape
+    dw = torch.empty((c, c, 3, 1) if axis == 0 else (c, c, 1, 3), dtype=torch.float32, device=x.device)
+    nb = size_query("erf_wgrad_workspace_bytes", c, c, 3, n * h * w)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    call("erf_conv1d_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _dt(x), n, h, w, c, axis, dilation, ws.data_ptr(), nb, _stream())
+    return dw
+
+
+def _conv1d_wgrad_fake(x, dz, axis, dilation):
+    c = x.shape[3]
+    return x.new_empty((c, c, 3, 1) if axis == 0 else (c, c, 1, 3), dtype=torch.float32)
+
+
+_register("conv1d_wgrad(Tensor x, Tensor dz, int axis, int dilation) -> Tensor", _conv1d_wgrad, _conv1d_wgrad_fake)
+
+
+# ------------------------------------------------------------------------------------------------ samplers and heads
+def _downsampler(x, packed, scale, shift, cout, relu):
+    _nhwc(x, "downsampler")
+    n, h, w, cin = x.shape
+    y = torch.empty((n, h // 2, w // 2, cout), dtype=x.dtype, device=x.device)
+    call("erf_downsampler", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), _dt(x), n, h, w, cin, cout,
+         int(relu), _stream())
+    return y
+
+
+_register("downsampler(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, int cout, bool relu) -> Tensor", _downsampler,
+          lambda x, packed, scale, shift, cout, relu: x.new_empty((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, cout)))
+
+
+def _stem(x_nchw, w, scale, shift, code, relu):
+    n, c, h, w_ = x_nchw.shape
+    if c != 3 or not x_nchw.is_contiguous():
+        raise ValueError("the initial block takes contiguous 3-channel NCHW images")
+    y = torch.empty((n, h // 2, w_ // 2, 16), dtype=torch.bfloat16 if code == BF16 else torch.float32, device=x_nchw.device)
+    call("erf_stem_downsampler", x_nchw.data_ptr(), _dt(x_nchw), y.data_ptr(), w.data_ptr(), _p(scale), _p(shift), code,
+         n, h, w_, int(relu), _stream())
+    return y
+
+
+_register("stem(Tensor x_nchw, Tensor w, Tensor? scale, Tensor? shift, int code, bool relu) -> Tensor", _stem,
+          lambda x, w, scale, shift, code, relu: x.new_empty((x.shape[0], x.shape[2] // 2, x.shape[3] // 2, 16),
+                                                             dtype=torch.bfloat16 if code == BF16 else torch.float32))
+
+
+def _upsampler(x, packed, scale, shift, cout, relu):
+    _nhwc(x, "upsampler")
+    n, h, w, cin = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, cout), dtype=x.dtype, device=x.device)
+    call("erf_upsampler_convT3x3s2", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), _dt(x), n, h, w,
+         cin, cout, int(relu), _stream())
+    return y
+
+
+_register("upsampler(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, int cout, bool relu) -> Tensor", _upsampler,
+          lambda x, packed, scale, shift, cout, relu: x.new_empty((x.shape[0], 2 * x.shape[1], 2 * x.shape[2], cout)))
+
+
+def _output_conv(x, packed, bias, nc, want_logits, logits_f32, label_bytes):
+    """Decoder.output_conv (ConvTranspose2d 2x2 stride 2): NCHW logits and / or the arg-max label map [N,2H,2W]
+    (label_bytes 0: none, 1: uint8, 8: int64).  An output that was not asked for comes back as an empty tensor."""
+    _nhwc(x, "output_conv")
+    n, h, w, cin = x.shape
+    logits = torch.empty((n, nc, 2 * h, 2 * w) if want_logits else (0,), dtype=torch.float32 if logits_f32 else x.dtype, device=x.device)
+    labels = torch.empty((n, 2 * h, 2 * w) if label_bytes else (0,), dtype=_label_dtype(label_bytes or 8), device=x.device)
+    call("erf_output_convT2x2s2", x.data_ptr(), packed.data_ptr(), bias.data_ptr(), logits.data_ptr() if want_logits else 0,
+         int(logits_f32), labels.data_ptr() if label_bytes else 0, label_bytes, _dt(x), n, h, w, nc, _stream())
+    return logits, labels
+
+
+def _output_conv_fake(x, packed, bias, nc, want_logits, logits_f32, label_bytes):
+    n, h, w, _ = x.shape
+    return (x.new_empty((n, nc, 2 * h, 2 * w) if want_logits else (0,), dtype=torch.float32 if logits_f32 else x.dtype),
+            x.new_empty((n, 2 * h, 2 * w) if label_bytes else (0,), dtype=_label_dtype(label_bytes or 8)))
+
+
+_register("output_conv(Tensor x, Tensor packed, Tensor bias, int nc, bool want_logits, bool logits_f32, int label_bytes) -> (Tensor, Tensor)",
+          _output_conv, _output_conv_fake)
+
+
+def _pointwise(x, packed, bias, nc, out_f32):
+    _nhwc(x, "pointwise")
+    n, h, w, cin = x.shape
+    y = torch.empty((n, nc, h, w), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    call("erf_pointwise_conv", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(bias), int(out_f32), _dt(x), n, h, w, cin, nc, _stream())
+    return y
+
+
+_register("pointwise(Tensor x, Tensor packed, Tensor? bias, int nc, bool out_f32) -> Tensor", _pointwise,
+          lambda x, packed, bias, nc, out_f32: x.new_empty((x.shape[0], nc, x.shape[1], x.shape[2]),
+                                                           dtype=torch.float32 if out_f32 else x.dtype))
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm / dropout pieces
+def _bn_apply(z, center, scale, shift, residual, mask, relu):
+    """y = act(((z - center) * scale + shift) * mask[n][c] + residual)"""
+    _nhwc(z, "bn_apply")
+    n, h, w, c = z.shape
+    y = torch.empty_like(z)
+    call("erf_bn_apply", z.data_ptr(), y.data_ptr(), _p(center), scale.data_ptr(), shift.data_ptr(), _p(residual), _p(mask),
+         _dt(z), n, h * w, c, int(relu), _stream())
+    return y
+
+
+_register("bn_apply(Tensor z, Tensor? center, Tensor scale, Tensor shift, Tensor? residual, Tensor? mask, bool relu) -> Tensor",
+          _bn_apply, _like_x)
+
+
+def _channel_sum(z):
+    c = z.shape[-1]
+    out = torch.empty(c, dtype=torch.float32, device=z.device)
+    ws = torch.empty(size_query("erf_bn_workspace_bytes", c), dtype=torch.uint8, device=z.device)
+    call("erf_channel_sum", z.data_ptr(), _dt(z), z.numel() // c, c, out.data_ptr(), ws.data_ptr(), _stream())
+    return out
+
+
+_register("channel_sum(Tensor z) -> Tensor", _channel_sum, lambda z: z.new_empty((z.shape[-1],), dtype=torch.float32))
+
+
+def _dropout2d_mask(like, n, c, p, seed):
+    mask = torch.empty((n, c), dtype=torch.float32, device=like.device)
+    call("erf_dropout2d_mask", mask.data_ptr(), n * c, float(p), seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    return mask
+
+
+_register("dropout2d_mask(Tensor like, int n, int c, float p, int seed) -> Tensor", _dropout2d_mask,
+          lambda like, n, c, p, seed: like.new_empty((n, c), dtype=torch.float32))
+
+
+# ------------------------------------------------------------------------------------------------ loss and metrics
+def _weighted_ce_fwd(logits, target, weight):
+    """[sum w*nll, sum w, their ratio] of NCHW logits against int64 targets [N,H,W] (CrossEntropyLoss2d, train/main.py:58-66)."""
+    n, c, h, w = logits.shape
+    if not logits.is_contiguous() or not target.is_contiguous() or target.dtype != torch.int64:
+        raise ValueError("weighted_ce_fwd: contiguous NCHW logits and contiguous int64 targets")
+    out = torch.empty(3, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(query("erf_ce_workspace_bytes"), dtype=torch.uint8, device=logits.device)
+    call("erf_weighted_ce_fwd", logits.data_ptr(), _dt(logits), target.data_ptr(), _p(weight), n, c, h * w, out.data_ptr(),
+         ws.data_ptr(), _stream())
+    return out
+
+
+_register("weighted_ce_fwd(Tensor logits, Tensor target, Tensor? weight) -> Tensor", _weighted_ce_fwd,
+          lambda logits, target, weight: logits.new_empty((3,), dtype=torch.float32))
+
+
+def _weighted_ce_bwd(logits, target, weight, coef):
+    n, c, h, w = logits.shape
+    dz = torch.empty_like(logits)
+    call("erf_weighted_ce_bwd", logits.data_ptr(), _dt(logits), target.data_ptr(), _p(weight), n, c, h * w, coef.data_ptr(),
+         dz.data_ptr(), _stream())
+    return dz
+
+
+_register("weighted_ce_bwd(Tensor logits, Tensor target, Tensor? weight, Tensor coef) -> Tensor", _weighted_ce_bwd,
+          lambda logits, target, weight, coef: torch.empty_like(logits))
+
+
+def _argmax_c(logits, label_bytes):
+    """outputs.max(1)[1] on NCHW-contiguous logits -> [N,H,W] (first maximum wins, as torch's)."""
+    if not logits.is_contiguous():
+        raise ValueError("argmax_c: contiguous NCHW logits")
+    n, c, h, w = logits.shape
+    lab = torch.empty((n, h, w), dtype=_label_dtype(label_bytes), device=logits.device)
+    call("erf_argmax_c", logits.data_ptr(), _dt(logits), lab.data_ptr(), label_bytes, n, c, h * w, _stream())
+    return lab
+
+
+_register("argmax_c(Tensor logits, int label_bytes) -> Tensor", _argmax_c,
+          lambda logits, label_bytes: logits.new_empty((logits.shape[0], logits.shape[2], logits.shape[3]), dtype=_label_dtype(label_bytes)))
+
+
+def _iou_hist_accumulate(pred, label, nc, hist):
+    """hist (int64 [nc*nc+1]) += confusion counts of (label, pred); eval/iouEval.py:18-60 as a histogram."""
+    if pred.numel() != label.numel():
+        raise ValueError("prediction and label maps differ in size")
+    for t in (pred, label):
+        if t.dtype not in (torch.uint8, torch.int64) or not t.is_contiguous():
+            raise TypeError("label maps must be contiguous uint8 or int64 tensors")
+    if hist.dtype != torch.int64 or hist.numel() < nc * nc + 1:
+        raise ValueError("hist: int64 [nc*nc+1]")
+    call("erf_iou_hist_accumulate", pred.data_ptr(), pred.element_size(), label.data_ptr(), label.element_size(),
+         pred.numel(), nc, hist.data_ptr(), _stream())
+
+
+_register("iou_hist_accumulate(Tensor pred, Tensor label, int nc, Tensor(a!) hist) -> ()", _iou_hist_accumulate,
+          lambda pred, label, nc, hist: None)
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def _adam_fused_arena(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale):
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != params.numel():
+            raise ValueError("adam_fused_arena_: four contiguous fp32 tensors of one size")
+    call("erf_adam_fused_arena", params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), params.numel(),
+         float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+_register("adam_fused_arena_(Tensor(a!) params, Tensor grads, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, "
+          "float beta2, float eps, float weight_decay, int step, float grad_scale) -> ()", _adam_fused_arena,
+          lambda *a: None)
