@@ -1,22 +1,23 @@
 #!/bin/bash
-# Regenerates profiles/r01_* on the GPU box: the unprofiled bench line, the rocprofv3 kernel-trace summary of the same
+# Regenerates profiles/$ROUND_* (ROUND defaults to r02) on the GPU box: the unprofiled bench line, the rocprofv3 kernel-trace summary of the same
 # command, the HBM-traffic counters (separate FETCH_SIZE / WRITE_SIZE passes) and the matrix-core utilisation pass.
-# Run from the repository root:  bash scripts/refresh_profiles.sh   (outputs land in gpurun_out/r01/, summaries in profiles/).
-# Through gpurun only gpurun_out/ comes back: afterwards  cp gpurun_out/r01/r01_* profiles/
+# Run from the repository root:  bash scripts/refresh_profiles.sh   (outputs land in gpurun_out/$ROUND/, summaries in profiles/).
+# Through gpurun only gpurun_out/ comes back: afterwards  cp gpurun_out/$ROUND/${ROUND}_* profiles/
 set -eo pipefail
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/r01
+ROUND=${ROUND:-r02}
+OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT" "$ROOT/profiles"
 timeout -k 10 300 python3 bench.py > "$OUT/bench_line.json"
-cp "$OUT/bench_line.json" profiles/r01_bench_line.json
+cp "$OUT/bench_line.json" profiles/${ROUND}_bench_line.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/trace.log" 2>&1
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --train-steps 2 --train-warmup 1 > "$OUT/pmc_fetch.log" 2>&1
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --train-steps 2 --train-warmup 1 > "$OUT/pmc_write.log" 2>&1
-timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 --train-steps 2 --train-warmup 1 > "$OUT/pmc_mfma.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-fp32 > "$OUT/trace.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-fp32 --steps 3 --warmup 1 --train-steps 2 --train-warmup 3 > "$OUT/pmc_fetch.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-fp32 --steps 3 --warmup 1 --train-steps 2 --train-warmup 3 > "$OUT/pmc_write.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-fp32 --steps 3 --warmup 1 --train-steps 2 --train-warmup 3 > "$OUT/pmc_mfma.log" 2>&1
 cd "$ROOT"
-cp "$(ls $OUT/trace/*/*kernel_stats.csv | tail -1)" profiles/r01_bench_kernel_stats.csv
-python3 scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" profiles/r01_pmc_traffic
-python3 scripts/pmc_mfma.py "$OUT/pmc_mfma" profiles/r01_pmc_mfma.csv > "$OUT/mfma.txt"
-cp profiles/r01_* "$OUT/"
-head -c 1500 profiles/r01_bench_line.json
+cp "$(ls $OUT/trace/*/*kernel_stats.csv | tail -1)" profiles/${ROUND}_bench_kernel_stats.csv
+python3 scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" profiles/${ROUND}_pmc_traffic
+python3 scripts/pmc_mfma.py "$OUT/pmc_mfma" profiles/${ROUND}_pmc_mfma.csv > "$OUT/mfma.txt"
+cp profiles/${ROUND}_* "$OUT/"
+head -c 1500 profiles/${ROUND}_bench_line.json
