@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--train-graph", action="store_true", help="N > 1: capture the training step (RCCL all-reduces included) into a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="auto mode: skip the training leg")
