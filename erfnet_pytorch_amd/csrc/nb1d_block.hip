@@ -71,7 +71,7 @@ constexpr int NW = 4;
 // register allocator (left to itself it parks weights in accumulation registers and copies them back to vector registers in
 // front of every use).  AW: the weight fragment lives in an accumulation register ("a") or a vector register ("v").
 // ZERO: first K-step, the sum starts from the inline constant 0.
-// Hazards the compiler cannot see inside asm: the B operand comes from an LDS read retired by s_waitcnt (no vector-ALU
+// Hazards the compiler cannot see inside asm: the pixel operand comes from an LDS read retired by s_waitcnt (no vector-ALU
 // producer); an accumulator is read by vector instructions only after at least four later matrix instructions were issued
 // (64+ cycles), or behind the explicit pause at the end of a phase.
 template <bool AW, bool ZERO>
