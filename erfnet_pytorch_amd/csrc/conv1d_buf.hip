@@ -485,8 +485,6 @@ static int launch_buf(BufParams p, int N, int H, int W, int axis, int* groups, h
     if (p.bz) {
         if (!p.stats || !post || !p.bmean || !p.binvstd) return ERF_EINVAL;
         if (p.bmask && axis != 0) return ERF_EUNSUPPORTED;       // the mask is per image: tiles must not mix images
-        // fp32 at 128 channels does not fit the register file with the BatchNorm-backward epilogue (216 bytes of scratch
-        // per lane); that instance is not built -- the caller runs the BatchNorm backward as its own pass.
         ERF_LAUNCH_BUF(true, 2)
     } else if (p.stats) { if (post) ERF_LAUNCH_BUF(true, 1) else ERF_LAUNCH_BUF(false, 1) }
     else { if (post) ERF_LAUNCH_BUF(true, 0) else ERF_LAUNCH_BUF(false, 0) }
