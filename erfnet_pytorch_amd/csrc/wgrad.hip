@@ -104,29 +104,59 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             }
         }
         __syncthreads();
+        // Both images are gathered in batches of U chunks per thread: all loads of a batch are issued before the first
+        // LDS store waits for one, so a step pays a few memory round trips instead of one per chunk (the trip counts are
+        // run-time values, which keeps the compiler from doing this itself).
+        constexpr int U = 4;
         // A: dz rows of the 32 output pixels
-        for (int id = tid; id < KPIX * ACH; id += 256) {
-            const int px = id / ACH, ch = id % ACH;
-            i32x4 v = {0, 0, 0, 0};
-            const int n = s_n[px];
-            if (n >= 0) {
-                const long long op = ((long long)n * p.Hout + s_i[px] * p.So + p.oh) * p.Wout + s_j[px] * p.So + p.ow;
-                v = *(const i32x4*)(dzg + op * p.lddz + ch * EPC);
+        for (int base = 0; base < KPIX * ACH; base += 256 * U) {
+            i32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = base + u * 256 + tid;
+                v[u] = i32x4{0, 0, 0, 0};
+                if (id < KPIX * ACH) {
+                    const int px = id / ACH, ch = id % ACH;
+                    const int n = s_n[px];
+                    if (n >= 0) {
+                        const long long op = ((long long)n * p.Hout + s_i[px] * p.So + p.oh) * p.Wout + s_j[px] * p.So + p.ow;
+                        v[u] = *(const i32x4*)(dzg + op * p.lddz + ch * EPC);
+                    }
+                }
             }
-            *(i32x4*)(a_lds + px * a_row + ch * 16) = v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = base + u * 256 + tid;
+                if (id < KPIX * ACH) *(i32x4*)(a_lds + (id / ACH) * a_row + (id % ACH) * 16) = v[u];
+            }
         }
         // B: gathered input pixels, one CIN-wide column block per tap
-        for (int id = tid; id < p.ntaps * KPIX * CH; id += 256) {
-            const int tap = id / (KPIX * CH), rem = id % (KPIX * CH);
-            const int px = rem / CH, ch = rem % CH;
-            i32x4 v = {0, 0, 0, 0};
-            const int n = s_n[px];
-            if (n >= 0) {
-                const int hi = s_i[px] * p.Si + p.dh[tap], wi = s_j[px] * p.Si + p.dw[tap];
-                if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
-                    v = *(const i32x4*)(xg + (((long long)n * p.Hin + hi) * p.Win + wi) * p.ldx + ch * EPC);
+        const int btotal = p.ntaps * KPIX * CH;
+        for (int base = 0; base < btotal; base += 256 * U) {
+            i32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = base + u * 256 + tid;
+                v[u] = i32x4{0, 0, 0, 0};
+                if (id < btotal) {
+                    const int tap = id / (KPIX * CH), rem = id % (KPIX * CH);
+                    const int px = rem / CH, ch = rem % CH;
+                    const int n = s_n[px];
+                    if (n >= 0) {
+                        const int hi = s_i[px] * p.Si + p.dh[tap], wi = s_j[px] * p.Si + p.dw[tap];
+                        if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
+                            v[u] = *(const i32x4*)(xg + (((long long)n * p.Hin + hi) * p.Win + wi) * p.ldx + ch * EPC);
+                    }
+                }
             }
-            *(i32x4*)(b_lds + px * b_row + (tap * CIN) * (int)sizeof(T) + ch * 16) = v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = base + u * 256 + tid;
+                if (id < btotal) {
+                    const int tap = id / (KPIX * CH), rem = id % (KPIX * CH);
+                    *(i32x4*)(b_lds + (rem / CH) * b_row + (tap * CIN) * (int)sizeof(T) + (rem % CH) * 16) = v[u];
+                }
+            }
         }
         __syncthreads();
 #pragma unroll

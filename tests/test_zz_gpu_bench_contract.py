@@ -1,0 +1,67 @@
+"""bench.py's one-line JSON contract, on small shapes: the keys the driver reads, the objects this repository adds
+(roofline, roofline_block, cpu_baseline, training, fp32) at N = 1, and at N = 2 (rehearsal: both ranks on the one GPU, gloo)
+the training step as the headline with the inference leg, the process group's world size and the per-bucket all-reduce
+times beside it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config"}
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_every_leg():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--train-steps", "2", "--train-warmup", "3",
+           "--height", "64", "--width", "128", "--batch", "2", "--train-batch", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert BASE_KEYS <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "bf16" and d["unit"] == "img/s"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["world_size"] == 1
+    assert "inference" in d["config"]["workload"] and d["config"]["hip_graph"] is True
+    assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "traffic" in rf and rf["avg_launch_us"] > 0
+    rb = d["roofline_block"]
+    assert rb["algorithmic_bytes_per_block"] * 2.5 == rb["launch_bytes_per_block"] and 0 < rb["frac"] < rf["frac"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    tr = d["training"]
+    assert tr["dtype"] == "bf16" and tr["config"]["hip_graph"] is True and tr["steps"] == 2 and tr["value"] > 0
+    assert tr["config"]["final_loss"] == tr["config"]["final_loss"]                 # finite
+    fp = d["fp32"]
+    assert fp["inference"]["dtype"] == "fp32" and fp["training"]["dtype"] == "fp32" and fp["training"]["value"] > 0
+
+
+def test_two_rank_line_reports_training_as_the_headline(tmp_path):
+    env = dict(os.environ, ERF_BENCH_REHEARSAL="1", ERF_BENCH_REHEARSAL_LIMIT="200")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--infer-steps", "2",
+           "--infer-warmup", "1", "--height", "64", "--width", "128", "--train-batch", "2", "--batch", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert BASE_KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert "training step" in d["config"]["workload"] and d["config"]["global_batch"] == 4
+    assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert "REHEARSAL" in d["data"]
+    inf = d["inference"]
+    assert "inference" in inf["config"]["workload"] and inf["steps"] == 2 and inf["value"] > 0
+    ar = d["allreduce"]
+    assert ar["ranks"] == 2 and len(ar["buckets"]) == 3 and all(b["ms"] > 0 and b["bytes"] == 4 * b["elements"] for b in ar["buckets"])
+    assert sum(b["elements"] for b in ar["buckets"]) <= 2_066_836
+    assert "cpu_baseline" not in d
