@@ -178,6 +178,71 @@ __device__ __forceinline__ void mfma_phase(const int* lb, const i32x4 (&wreg)[CT
 }
 
 
+// GEMM 1 (the 3x1 convolution over the input tile) with every pixel fragment read ONCE.  A tap shifts the pixel index by
+// TC, a whole number S of 16-pixel tiles, so fragment (pixel tile pt, tap t, chunk kc) IS fragment (LDS tile pt + t S, kc):
+// walking the LDS tiles j = 0 .. PTW + 2S - 1 and feeding each fragment to the (up to) three accumulators pt = j - t S it
+// belongs to needs (PTW + 2S) / (3 PTW) of the reads of mfma_phase -- 10 instead of 24 per chunk at PTW = 8 -- and LDS reads
+// are what bounds this phase.  Every accumulator still receives its K-steps in the order tap 0, 1, 2 / chunks ascending, so
+// the sums are bit-identical to mfma_phase's.
+template <int C, int TC, int PTW, int CTW, typename EPI>
+__device__ __forceinline__ void mfma_phase_shared(const int* lb, const i32x4 (&wreg)[CTW][(3 * (C / 8) + 3) / 4], f32x4 (&acc)[PTW][CTW],
+                                                  EPI&& epi) {
+    constexpr int CH = C / 8;
+    constexpr int PIXB = C * 2;
+    constexpr int KPT = CH / 4;                        // K-steps per tap
+    constexpr int NCL = (CH < 16 ? CH : 16) / 4;
+    constexpr int S = TC / 16;
+    constexpr int NJ = PTW + 2 * S;
+    constexpr int NR = NJ * KPT;                       // fragment reads of the phase
+    constexpr int GS = NR % 6 == 0 ? 6 : NR % 5 == 0 ? 5 : NR % 4 == 0 ? 4 : NR % 3 == 0 ? 3 : 2;
+    constexpr int NG = NR / GS;
+    static_assert(CH >= 4 && CH % 4 == 0 && TC % 16 == 0 && NR % GS == 0, "shared-fragment phase");
+    i32x4 bb[2][GS];
+    auto issue = [&](auto gi, i32x4* dst) {
+        static_for<0, GS>([&](auto e) {
+            constexpr int r = decltype(gi)::value * GS + decltype(e)::value;
+            constexpr int j = r / KPT, kc = r % KPT;
+            constexpr int imm = j * 16 * PIXB + (CH > 16 ? ((kc * 4) & ~15) * 16 : 0);
+            static_assert(imm < 65536, "ds offset field");
+            dst[decltype(e)::value] = lds_read_b128<imm>(lb[kc % NCL]);
+        });
+    };
+    // pixel tiles whose last K-step (fragment j = pt + 2S, last chunk) lies before read r
+    auto done_before = [](int r) constexpr { const int n = r / KPT - 2 * S; return n < 0 ? 0 : (n > PTW ? PTW : n); };
+    issue(std::integral_constant<int, 0>{}, bb[0]);
+    static_for<0, NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        i32x4* cb = bb[g & 1];
+        if constexpr (g + 1 < NG) {
+            issue(std::integral_constant<int, g + 1>{}, bb[(g + 1) & 1]);
+            wait_lgkm<GS>();
+        } else {
+            wait_lgkm<0>();
+        }
+        static_for<0, GS>([&](auto e) { tie_reg(cb[decltype(e)::value]); });
+        static_for<0, GS>([&](auto e) {
+            constexpr int r = g * GS + decltype(e)::value;
+            constexpr int j = r / KPT, kc = r % KPT;
+            const i32x4 b = cb[decltype(e)::value];
+            static_for<0, 3>([&](auto ti) {
+                constexpr int tap = decltype(ti)::value;
+                constexpr int pt = j - tap * S;
+                if constexpr (pt >= 0 && pt < PTW) {
+                    constexpr int ks = tap * KPT + kc;
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c)
+                        acc[pt][c] = mma_step<T>(wreg[c][ks], b, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pt][c]);
+                }
+            });
+        });
+        constexpr int done_lo = g == 0 ? 0 : done_before((g - 1) * GS);
+        constexpr int done_hi = done_before(g * GS);
+        static_for<done_lo, done_hi>([&](auto pt) { epi(pt); });
+    });
+    static_for<done_before((NG - 1) * GS), PTW>([&](auto pt) { epi(pt); });
+}
+
+
 template <int C, int WM, int WN, int M, int TC, int KI, int OCC, bool POST>
 __global__ __launch_bounds__(WM * WN * 64, OCC)
 void conv1d_pair_kernel(const PairParams p) {
@@ -354,6 +419,7 @@ void conv1d_pair_kernel(const PairParams p) {
             }
         };
         if (p.dbg & 4) static_for<0, PTW>(ep1);
+        else if constexpr (CH >= 4 && TB * 16 == TC && (TB == 1 || WM == 1)) mfma_phase_shared<C, TC, PTW, CTW>(lb, wA, acc, ep1);
         else mfma_phase<C, TC, PTW, CTW, ImmIn>(lb, wA, acc, q, ep1);
         if (g.jhi < TC) {                             // wave-uniform and rare: tiles at the right image edge
 #pragma unroll
