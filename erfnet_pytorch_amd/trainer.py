@@ -235,8 +235,6 @@ class Trainer:
                 self._seen.add(key)
                 return self._step_eager(images, targets)
             entry = self._capture(key, images, targets)
-            if entry is None:
-                return self._step_eager(images, targets)
         graph, gx, gt, loss, outputs = entry
         gx.copy_(images)
         gt.copy_(targets)
@@ -258,18 +256,8 @@ class Trainer:
         graph = torch.cuda.CUDAGraph()
         # everything the step changed on the HOST during capture is undone below: the capture launches nothing
         host = (self._step_host, self._epoch[0])
-        try:
-            with torch.cuda.graph(graph):
-                loss, outputs = self._step_eager(gx, gt)
-        except Exception as exc:                                      # e.g. a collective library that cannot be captured
-            import warnings
-            self._step_host, self._epoch[0] = host
-            self._pending = []
-            ag.flush_bias_sums()
-            self.use_graph = False
-            warnings.warn(f"Trainer: the step could not be captured into a HIP graph ({type(exc).__name__}: {exc}); "
-                          "continuing with kernel-by-kernel launches")
-            return None
+        with torch.cuda.graph(graph):                                 # anything that cannot be captured raises here
+            loss, outputs = self._step_eager(gx, gt)
         self._step_host, self._epoch[0] = host
         entry = (graph, gx, gt, loss, outputs)
         self._graphs[key] = entry

@@ -134,3 +134,4 @@ def test_adam_with_device_step_equals_adam_with_host_step():
         # place of the fp32 factor, one ulp of the update
         assert float((pa - pb).abs().max()) <= 2e-7 * float(pa.abs().max())
         assert torch.equal(ma, mb) and torch.equal(va, vb)
+
