@@ -35,3 +35,6 @@ int conv1d_buf_max_groups();
 // ERF_EUNSUPPORTED for every other shape (nothing launched).
 int nb1d_block_launch(const void* x, void* y, const void* const* packed4, const float* tab, int dtype, int N, int H, int W, int C,
                       int dilation, hipStream_t stream);
+// The same block for C = 16 (nb1d_block16.hip): same arguments, same status codes.
+int nb1d_block16_launch(const void* x, void* y, const void* const* packed4, const float* tab, int dtype, int N, int H, int W, int C,
+                        int dilation, hipStream_t stream);

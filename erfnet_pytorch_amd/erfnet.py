@@ -24,7 +24,9 @@ from ._lib import AXIS_H, AXIS_W, BF16, F32
 
 BN_EPS = 1e-3
 FUSE_PAIRS = True     # inference: one launch per conv3x1 -> conv1x3 pair where the library supports it
-FUSE_BLOCKS = False   # inference: one launch per whole non_bottleneck_1d block (bit-identical to the pair path, measured slower: opt-in)
+# inference: channel counts whose dilation-1 non_bottleneck_1d blocks run as ONE launch (bit-identical to the pair path).
+# 64 is supported but measured slower than two pair launches, so it stays opt-in: FUSE_BLOCKS = (16, 64).
+FUSE_BLOCKS = (16,)
 
 
 def _versions(mod: nn.Module):
@@ -134,7 +136,7 @@ class non_bottleneck_1d(_Block):
     def forward_nhwc(self, x):
         c = self._cached(ops.dt(x))
         d = self.dilated
-        if FUSE_BLOCKS and d == 1 and x.dtype == torch.bfloat16 and self.chann == 64:
+        if d == 1 and x.dtype == torch.bfloat16 and self.chann in FUSE_BLOCKS:
             return ops.T.nb1d_block(x, c["w1"], c["w2"], c["w3"], c["w4"], c["table"], d)
         if FUSE_PAIRS:
             # one launch per conv3x1 -> conv1x3 pair where the library takes the shape, else two (decided inside the op)

@@ -111,7 +111,7 @@ def _nb1d_block(x, w1, w2, w3, w4, table, dilation):
     rc = query("erf_nb1d_block_infer", x.data_ptr(), y.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), w4.data_ptr(),
                table.data_ptr(), _dt(x), n, h, w, c, dilation, _stream())
     if rc == -2:
-        raise NotImplementedError("nb1d_block takes bf16, 64 channels, dilation 1 (erf_nb1d_block_infer); use conv1d_pair twice")
+        raise NotImplementedError("nb1d_block takes bf16, 16 or 64 channels, dilation 1 (erf_nb1d_block_infer); use conv1d_pair twice")
     if rc != 0:
         raise RuntimeError(f"erf_nb1d_block_infer failed with status {rc}")
     return y

@@ -1,25 +1,33 @@
-"""Median per-launch time of the whole-block kernel at the benchmark shape (16 x 128 x 256 x 64)."""
+"""Median per-block time of the one-launch block kernel and of the two-pair-launch path.
+usage: block_time.py [channels=64] -- shapes: 64 -> 16x128x256, 16 -> 16x256x512 (the benchmark's maps)."""
 import sys
 sys.path.insert(0, ".")
 import torch
 from erfnet_pytorch_amd import erfnet as E
 from oracle import erfnet_oracle as O
 dev = torch.device("cuda:0")
-c = 64
+c = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+hw = (128, 256) if c == 64 else (256, 512)
 blk = E.non_bottleneck_1d(c, 0.03, 1)
 sd = O.synthetic_state(O.nb_template("encoder.layers.1", c))
 blk.load_state_dict({k[len("encoder.layers.1."):]: v for k, v in sd.items()})
 blk = blk.to(dev).eval()
-E.FUSE_BLOCKS = True
-x = torch.relu(torch.randn(16, 128, 256, c, device=dev)).to(torch.bfloat16)
-ts = []
-with torch.no_grad():
+E.FUSE_BLOCKS = (16, 64)
+x = torch.relu(torch.randn(16, *hw, c, device=dev)).to(torch.bfloat16)
+for fused in ((16, 64), ()):
+  E.FUSE_BLOCKS = fused
+  ts = []
+  with torch.no_grad():
     for i in range(14):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); y = blk.forward_nhwc(x); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
-ts = sorted(ts[4:])
-print(f"median {ts[len(ts)//2]:.1f} us  min {ts[0]:.1f}")
+    if fused:
+        y_fused = y
+  ts = sorted(ts[4:])
+  print(f"{'one launch' if fused else 'two pair launches'}: median {ts[len(ts)//2]:.1f} us  min {ts[0]:.1f}", flush=True)
+print("bit-identical:", torch.equal(y, y_fused))
+y = y_fused
 import os
 if int(os.environ.get("ERF_BLOCK_DBG", "0")) & 256:
     st = y.view(torch.int64).reshape(-1)[:512].reshape(256, 2).cpu().double()

@@ -1,4 +1,4 @@
-"""erf_nb1d_block_infer (a whole non_bottleneck_1d block in one launch, bf16, 64 channels, dilation 1) against the path the
+"""erf_nb1d_block_infer (a whole non_bottleneck_1d block in one launch, bf16, 64 or 16 channels, dilation 1) against the path the
 modules use by default (two conv1d_pair launches): the same fragments meet the same matrix instructions in the same order, so
 the outputs must be BIT-IDENTICAL, including on tiles that touch the image border, ragged sizes and images smaller than a
 tile.  The golden block output of the reference (train/erfnet.py:58-74, eval mode) is checked through the same entry point."""
@@ -22,7 +22,7 @@ def _block(c=64, d=1):
 
 def _run(blk, x, fused):
     old = E.FUSE_BLOCKS
-    E.FUSE_BLOCKS = fused
+    E.FUSE_BLOCKS = (16, 64) if fused else ()
     try:
         with torch.no_grad():
             return blk.forward_nhwc(x)
@@ -31,12 +31,13 @@ def _run(blk, x, fused):
 
 
 @pytest.mark.parametrize("shape", [(1, 8, 32), (1, 16, 64), (2, 24, 40), (1, 13, 37), (3, 40, 100), (2, 7, 5), (1, 2, 3), (1, 1, 1),
-                                   (1, 128, 256), (5, 64, 96)])
-def test_block_kernel_is_bit_identical_to_the_pair_path(shape):
+                                   (1, 128, 256), (5, 64, 96), (1, 9, 130), (2, 70, 66)])
+@pytest.mark.parametrize("chann", [64, 16])
+def test_block_kernel_is_bit_identical_to_the_pair_path(shape, chann):
     n, h, w = shape
-    blk = _block()
+    blk = _block(chann)
     g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
-    x = torch.relu(torch.randn(n, h, w, 64, generator=g)).to(DEV, torch.bfloat16)
+    x = torch.relu(torch.randn(n, h, w, chann, generator=g)).to(DEV, torch.bfloat16)
     a = _run(blk, x, True)
     b = _run(blk, x, False)
     a2 = _run(blk, x, True)                        # and it is deterministic
@@ -63,6 +64,13 @@ def test_block_kernel_declines_what_it_does_not_cover():
     assert ops.nb1d_block(x128, w4, c["table"], 1) is None                    # channel count
     with pytest.raises(RuntimeError):
         ops.nb1d_block(x, w4, c["table"], 1, out=x)                           # in place is refused
+    x16 = torch.zeros(1, 8, 32, 16, device=DEV, dtype=torch.bfloat16)
+    blk16 = _block(16)
+    c16 = blk16._cached(ops.dt(x16))
+    w16 = (c16["w1"], c16["w2"], c16["w3"], c16["w4"])
+    assert ops.nb1d_block(x16, w16, c16["table"], 1) is not None
+    assert ops.nb1d_block(x16, w16, c16["table"], 2) is None
+    assert ops.nb1d_block(x16.float(), w16, c16["table"], 1) is None
 
 
 def test_block_kernel_vs_reference_golden():
