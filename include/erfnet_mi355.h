@@ -76,9 +76,10 @@ int erf_conv1d_pair(const void* x, void* y, const void* packed_a, const void* pa
  * x is read once and y written once; the three intermediate maps stay on the chip.  Results are bit-identical to two
  * erf_conv1d_pair calls.  packed1..4: mode-0 packed weights of the four convolutions; table: fp32 [4][2][C] in device memory,
  * row k = {scale of convolution k (1 where it has none), shift of convolution k}.  x and y must not alias.
- * Takes bf16, C = 64, dilation 1; returns ERF_EUNSUPPORTED (-2) without launching otherwise: issue two erf_conv1d_pair.
- * The result is bit-identical to those two launches; on MI355X it currently takes longer than they do (one wave per SIMD
- * cannot hide its own epilogues), so prefer it only where the number of launches matters. */
+ * Takes bf16, C = 16 or C = 64, dilation 1; returns ERF_EUNSUPPORTED (-2) without launching otherwise: issue two
+ * erf_conv1d_pair.  The result is bit-identical to those two launches.  On MI355X the C = 16 kernel is the faster way
+ * (45 vs 70 us at 16 x 256 x 512); the C = 64 kernel currently takes longer than the two launches (one wave per SIMD cannot
+ * hide its own epilogues), so prefer that one only where the number of launches matters. */
 int erf_nb1d_block_infer(const void* x, void* y, const void* packed1, const void* packed2, const void* packed3, const void* packed4,
                          const float* table, int dtype, int N, int H, int W, int C, int dilation, void* stream);
 
