@@ -46,6 +46,11 @@ __device__ __forceinline__ int pack_bf16x2(float lo, float hi) {
     const f32x2 v{lo, hi};
     return __builtin_bit_cast(int, __builtin_convertvector(v, bf16x2_t));
 }
+// ReLU of two packed bf16 values: bf16 is sign-magnitude, so max with 0 as 16-bit integers clears exactly the negative ones.
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+__device__ __forceinline__ int relu_bf16x2(int packed) {
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, packed), i16x2{0, 0}));
+}
 __device__ __forceinline__ i32x2 pack_bf16x4(const f32x4& v) {
     i32x2 r;
     r[0] = pack_bf16x2(v[0], v[1]);

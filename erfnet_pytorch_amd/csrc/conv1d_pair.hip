@@ -277,6 +277,9 @@ void conv1d_pair_kernel(const PairParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int q = lane >> 4, r16 = lane & 15;
+#ifdef ERF_DEBUG
+    const uint64_t tentry = __builtin_amdgcn_s_memtime();
+#endif
 
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((const char*)p.x - p.pad, (p.dbg & 1) ? 0u : p.bytes + p.pad);
     const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y, (p.dbg & 2) ? 0u : p.bytes);
@@ -392,6 +395,16 @@ void conv1d_pair_kernel(const PairParams p) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KI) : "memory");
     ERF_LDS_BARRIER();
 
+#ifdef ERF_DEBUG
+    // diagnostic build only (ERF_PAIR_DBG & 256): shader cycles per section of the tile loop, summed over this workgroup's
+    // tiles, written over the head of y (scripts/pair_phase_time.py reads them)
+    uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = __builtin_amdgcn_s_memtime();
+    const uint64_t tstart = tprev;
+#define PAIR_STAMP(i) { const uint64_t tn = __builtin_amdgcn_s_memtime(); st[i] += tn - tprev; tprev = tn; }
+#else
+#define PAIR_STAMP(i)
+#endif
     int cur = 0;
     for (; tile < tile_end; tile += G, cur ^= 1) {
         const int boff = cur * BUFB;
@@ -430,7 +443,9 @@ void conv1d_pair_kernel(const PairParams p) {
                 }
             }
         }
+        PAIR_STAMP(0)
         ERF_LDS_BARRIER();                 // intermediate complete; input tile no longer read
+        PAIR_STAMP(1)
 
         // ---------------- GEMM 2: 1x3 over the intermediate rows
         // accumulators -> LDS as [pixel][C] bf16 (in the consumed input buffer)
@@ -449,7 +464,9 @@ void conv1d_pair_kernel(const PairParams p) {
         };
         if (p.dbg & 4) static_for<0, PTW>(ep2);
         else mfma_phase<C, TC, PTW, CTW, ImmMid>(lb2, wB, acc, q, ep2);
+        PAIR_STAMP(2)
         ERF_LDS_BARRIER();                 // staging complete; intermediate no longer read
+        PAIR_STAMP(3)
 
         // ---------------- coalesced read-back (+ residual, ReLU)
         i32x4 outv[NS];
@@ -475,7 +492,9 @@ void conv1d_pair_kernel(const PairParams p) {
                 outv[s] = ChunkOps<T>::pack(f);
             }
         }
+        PAIR_STAMP(4)
         ERF_LDS_BARRIER();                 // staging consumed: the buffer may take tile k+2
+        PAIR_STAMP(5)
 
         const uint32_t out_soff = g.out_soff;
         g = g1;
@@ -486,9 +505,19 @@ void conv1d_pair_kernel(const PairParams p) {
         for (int s = 0; s < NS; ++s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[s]), rs_y, ooff[s], out_soff, 0);
         // the data registers of a 16-byte buffer store must not be rewritten in the cycles right after its issue
         // (the compiler does not guard stores with an SGPR offset): pause before anything else runs
+        PAIR_STAMP(6)
         asm volatile("s_nop 7\n\ts_barrier" ::: "memory");             // ... and everyone else's
+        PAIR_STAMP(7)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
+#ifdef ERF_DEBUG
+    if ((p.dbg & 256) && (tid & 63) == 0) {
+        uint64_t* o = (uint64_t*)p.y + (blockIdx.x * NW + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = __builtin_amdgcn_s_memtime() - tstart;
+        o[9] = tstart - tentry;                                          // prologue: weights, addressing, first two tiles
+    }
+#endif
 #endif
 }
 

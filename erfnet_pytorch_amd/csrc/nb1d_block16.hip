@@ -73,8 +73,6 @@ static_assert(((NPT1 + NW - 1) / NW) * NW * 16 * PIXB < 65536, "ds offset field"
 // wr: address of its 8 output bytes (channels 4 q .. 4 q + 3 of pixel r16).  MASK: pixels outside the image become zero;
 // m0 = this lane's pixel index in pixel tile `wave` (< 64, so row 0 of the region), (hb, wb) = image coordinates of the
 // region's first pixel.
-typedef __attribute__((ext_vector_type(2))) short i16x2;
-
 template <int NPT, bool RELU, bool MASK>
 __device__ __forceinline__ void conv_phase16(char* smem, int rd0, int rd1, int st1, int wr, const i32x4& w0, const i32x4& w1, const f32x4& sc,
                                              const f32x4& sh, int wave, int m0, int hb, int wb, int H, int W) {
@@ -101,9 +99,8 @@ __device__ __forceinline__ void conv_phase16(char* smem, int rd0, int rd1, int s
         if constexpr (RELU) {
             // bf16 is sign-magnitude: max with 0 as 16-bit integers is ReLU on the rounded values (rounding keeps the sign).
             // (Scalars on purpose: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler.)
-            const i16x2 z{0, 0};
-            o0 = __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, o0), z));
-            o1 = __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, o1), z));
+            o0 = relu_bf16x2(o0);
+            o1 = relu_bf16x2(o1);
         }
         i32x2 o{o0, o1};
         if constexpr (MASK) {
@@ -242,7 +239,7 @@ void nb1d_block16_kernel(const NbBlock16Params p) {
             const f32x2 sum = f32x2{__uint_as_float(a << 16), __uint_as_float(a & 0xFFFF0000u)} +
                               f32x2{__uint_as_float(r << 16), __uint_as_float(r & 0xFFFF0000u)};
             const int pk = pack_bf16x2(sum[0], sum[1]);
-            out[d] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), i16x2{0, 0}));
+            out[d] = (uint32_t)relu_bf16x2(pk);
         }
         __builtin_amdgcn_raw_buffer_store_b128(out, rs_y, ooff[s], 0, 0);
     }
