@@ -12,6 +12,7 @@
 // order and scatters them into the torch weight layout (no atomics: bit-reproducible).
 #include "common.cuh"
 #include "train.cuh"
+#include "conv1d_tile.cuh"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -190,6 +191,159 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---- One tap per workgroup ("tap-split") ----------------------------------------------------------------------------
+// The kernel above is bound by the latency of a step (index arithmetic, gather, LDS, fragments: ~4 us for ~0.2 us of
+// matrix work) and cannot hide it with more workgroups, because every workgroup owns a whole [rows][taps * CIN] tile of
+// partial sums: twice the workgroups is twice the partial-sum traffic.  Here a workgroup owns ONE tap's [rows][CIN]
+// column block of that tile: grid = (pixel slices, taps of all phases).  The partial sums of a slice are the same
+// bytes as before, but 3..9 times as many workgroups are in flight behind them (and the four phases of a transposed
+// convolution are one launch).  A step takes 128 (bf16) / 64 (fp32) base pixels, every thread decodes its own pixels
+// with multiply-high divisions and has all its loads in flight before the first LDS store.  CIN = 16 has a single column
+// tile: the four waves then split the pixel sub-steps and meet in LDS (fixed order) before the partial tile is written.
+struct WTapEntry { float* partial; int oh, ow, dh, dw, col0, ncols_pad; };
+struct WTapParams {
+    const void* x;
+    const void* dz;
+    int N, Hin, Win, ldx, xoff, Hb, Wb, Hout, Wout, lddz, dzoff, Si, So;
+    unsigned P;                     // base pixels
+    int ppw;                        // base pixels per workgroup (a multiple of 128)
+    int rows_pad;
+    FastDiv fW, fH;
+    WTapEntry e[GC_MAX_TAPS];
+};
+
+template <typename T, int CIN, int COT>
+struct WTapCfg {
+    static constexpr int EPC = Elem<T>::EPC;
+    static constexpr int KPIX = 16 * EPC;                         // 128 pixels (bf16) / 64 (fp32) per step
+    static constexpr int A_ROW = COT * 16 * (int)sizeof(T) + 16;  // LDS row pitch: + 16 B spreads the transposed reads over the banks
+    static constexpr int B_ROW = CIN * (int)sizeof(T) + 16;
+    static constexpr int LDS = KPIX * (A_ROW + B_ROW);
+};
+
+template <typename T, int CIN, int COT>
+__global__ __launch_bounds__(256) void wgrad_tap_kernel(const WTapParams p) {
+    using Cfg = WTapCfg<T, CIN, COT>;
+    constexpr int EPC = Cfg::EPC, KPIX = Cfg::KPIX, A_ROW = Cfg::A_ROW, B_ROW = Cfg::B_ROW;
+    constexpr int SUB = Elem<T>::KSTEP;                 // pixels one mma_step consumes
+    constexpr int CH = CIN / EPC, ACH = COT * 16 / EPC;
+    constexpr int NCT = CIN / 16;                       // column tiles of this tap
+    constexpr int WK = NCT >= 4 ? 1 : 4 / NCT;          // wave groups that split the pixel sub-steps
+    constexpr int CPW = NCT >= 4 ? NCT / 4 : 1;         // column tiles per wave
+    constexpr int NA = KPIX * ACH / 256, NB = KPIX * CH / 256;
+    static_assert(CIN % 16 == 0 && (NCT >= 4 ? NCT % 4 == 0 : 4 % NCT == 0), "column tiles must divide over four waves");
+    static_assert(NA * 256 == KPIX * ACH && NB * 256 == KPIX * CH, "whole chunks per thread");
+    static_assert(WK == 1 || 4 * COT * 1024 <= Cfg::LDS, "cross-wave sum must fit the staging buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const a_lds = smem;
+    char* const b_lds = smem + KPIX * A_ROW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WTapEntry& e = p.e[blockIdx.y];
+    const T* const xg = (const T*)p.x + p.xoff;
+    const T* const dzg = (const T*)p.dz + p.dzoff;
+    const unsigned pixbeg = blockIdx.x * (unsigned)p.ppw;
+    const unsigned pixend = pixbeg + (unsigned)p.ppw < p.P ? pixbeg + (unsigned)p.ppw : p.P;
+
+    f32x4 acc[COT][CPW];
+#pragma unroll
+    for (int r = 0; r < COT; ++r)
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (unsigned pix0 = pixbeg; pix0 < pixend; pix0 += KPIX) {
+        i32x4 va[NA], vb[NB];
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int id = u * 256 + tid;
+            const unsigned pix = pix0 + id / ACH;
+            va[u] = i32x4{0, 0, 0, 0};
+            if (pix < pixend) {
+                const unsigned rest = fast_div(pix, p.fW);
+                const int j = (int)(pix - rest * p.fW.div);
+                const unsigned n = fast_div(rest, p.fH);
+                const int i = (int)(rest - n * p.fH.div);
+                const long long op = ((long long)n * p.Hout + i * p.So + e.oh) * p.Wout + j * p.So + e.ow;
+                va[u] = *(const i32x4*)(dzg + op * p.lddz + (id % ACH) * EPC);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int id = u * 256 + tid;
+            const unsigned pix = pix0 + id / CH;
+            vb[u] = i32x4{0, 0, 0, 0};
+            if (pix < pixend) {
+                const unsigned rest = fast_div(pix, p.fW);
+                const int j = (int)(pix - rest * p.fW.div);
+                const unsigned n = fast_div(rest, p.fH);
+                const int i = (int)(rest - n * p.fH.div);
+                const int hi = i * p.Si + e.dh, wi = j * p.Si + e.dw;
+                if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
+                    vb[u] = *(const i32x4*)(xg + (((long long)n * p.Hin + hi) * p.Win + wi) * p.ldx + (id % CH) * EPC);
+            }
+        }
+        __syncthreads();                              // the previous step's fragments are consumed
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int id = u * 256 + tid;
+            *(i32x4*)(a_lds + (id / ACH) * A_ROW + (id % ACH) * 16) = va[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int id = u * 256 + tid;
+            *(i32x4*)(b_lds + (id / CH) * B_ROW + (id % CH) * 16) = vb[u];
+        }
+        __syncthreads();
+        const int wk = WK == 1 ? 0 : wave % WK;
+#pragma unroll
+        for (int kk = 0; kk < KPIX / (SUB * WK); ++kk) {
+            const int kb = (kk * WK + wk) * SUB;
+            i32x4 af[COT];
+#pragma unroll
+            for (int r = 0; r < COT; ++r) af[r] = load_frag<T>(a_lds, A_ROW, r * 16, kb, lane);
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int ct = WK == 1 ? wave + 4 * c : wave / WK;
+                const i32x4 bf = load_frag<T>(b_lds, B_ROW, ct * 16, kb, lane);
+#pragma unroll
+                for (int r = 0; r < COT; ++r) acc[r][c] = mma_step<T>(af[r], bf, acc[r][c]);
+            }
+        }
+    }
+
+    if (WK > 1) {                                     // the wave groups of a column tile meet in LDS, summed in group order
+        __syncthreads();
+        f32x4* const red = (f32x4*)smem;
+#pragma unroll
+        for (int r = 0; r < COT; ++r) red[(wave * COT + r) * 64 + lane] = acc[r][0];
+        __syncthreads();
+        if (wave % WK != 0) return;
+#pragma unroll
+        for (int r = 0; r < COT; ++r) {
+            f32x4 s = red[(wave * COT + r) * 64 + lane];
+#pragma unroll
+            for (int g = 1; g < WK; ++g) {
+                const f32x4 o = red[((wave + g) * COT + r) * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += o[k];
+            }
+            acc[r][0] = s;
+        }
+    }
+    // this tap's column block of the slice's partial tile [rows_pad][ncols_pad]
+    float* const out = e.partial + (long long)blockIdx.x * p.rows_pad * e.ncols_pad + e.col0;
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int ct = WK == 1 ? wave + 4 * c : wave / WK;
+#pragma unroll
+        for (int r = 0; r < COT; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[(long long)(r * 16 + q * 4 + k) * e.ncols_pad + ct * 16 + j] = acc[r][c][k];
+    }
+}
+
 // dW[map(row, tap, ci)] = sum_wg partial[wg][row][tap*CIN + ci]
 // Block = E consecutive elements x 256 / E slices of the workgroup range; every slice sums its partials in a
 // fixed order (four chains, so the loads overlap), the slices meet in LDS and are added in slice order.
@@ -357,12 +511,46 @@ static void plan(long long P, size_t tile_bytes, int* nwg, int* spw) {
     *nwg = (int)((steps + s - 1) / s);
 }
 
+// ---- tap-split path: which shapes it takes and how it cuts the pixel range
+static bool tap_instance(int cin, int cot) {
+    switch (cin) {
+        case 16: return cot == 1 || cot == 2 || cot == 3 || cot == 5 || cot == 8;
+        case 64: return cot == 1 || cot == 4;
+        case 128: return cot == 1 || cot == 2 || cot == 4 || cot == 8;
+    }
+    return false;
+}
+static bool tap_path(int rows, int cin, long long P) {
+    static const int off = erf_debug_env("ERF_WGRAD_TAP_OFF", 0);
+    return !off && P > 0 && P < (1LL << 31) - 65536 && tap_instance(cin, (rows + 15) / 16);
+}
+// About eight resident workgroups per CU over the taps of the largest phase, at least two steps each, and at most
+// 12 MB of partial sums per phase.
+static void tap_plan(long long P, size_t tile_bytes, int max_taps, int* nwg, int* ppw) {
+    long long nk = 2048 / (max_taps > 0 ? max_taps : 1);
+    const long long cap = (long long)((12u << 20) / (tile_bytes ? tile_bytes : 1));
+    if (nk > cap) nk = cap;
+    if (nk < 1) nk = 1;
+    long long per = (P + nk - 1) / nk;
+    per = (per + 127) / 128 * 128;
+    if (per < 256) per = 256;
+    *ppw = (int)per;
+    *nwg = (int)((P + per - 1) / per);
+}
+
 size_t wgrad_workspace_bytes(int rows, int cin, int max_taps_per_phase, long long base_pixels) {
     int nwg, spw;
     const int rows_pad = (rows + 15) / 16 * 16;
     const int ncols_pad = (max_taps_per_phase * cin + 15) / 16 * 16;
-    plan(base_pixels, (size_t)rows_pad * ncols_pad * sizeof(float), &nwg, &spw);
-    return (size_t)nwg * rows_pad * ncols_pad * sizeof(float);
+    const size_t tile = (size_t)rows_pad * ncols_pad * sizeof(float);
+    plan(base_pixels, tile, &nwg, &spw);
+    size_t need = (size_t)nwg * tile;
+    if (tap_path(rows, cin, base_pixels)) {          // a caller's workspace serves either path
+        int nk, ppw;
+        tap_plan(base_pixels, tile, max_taps_per_phase, &nk, &ppw);
+        if ((size_t)nk * tile > need) need = (size_t)nk * tile;
+    }
+    return need;
 }
 
 template <typename T, int CIN, int COT, int CPW>
@@ -405,16 +593,80 @@ static int dispatch(const WgradParams& wp, int dtype, int cin, int cot, int cpw,
     return ERF_EUNSUPPORTED;
 }
 
+template <typename T, int CIN, int COT>
+static int launch_tap(const WTapParams& tp, int nwg, int ntaps, hipStream_t stream) {
+    using Cfg = WTapCfg<T, CIN, COT>;
+    auto kern = wgrad_tap_kernel<T, CIN, COT>;
+    if (Cfg::LDS > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess)
+        return ERF_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(nwg, ntaps), dim3(256), Cfg::LDS, stream, tp);
+    return erf_check_launch();
+}
+
+#define WT_CASE(CINV, COTV)                                                                               \
+    if (cin == CINV && cot == COTV)                                                                       \
+        return dtype == 1 ? launch_tap<bf16raw, CINV, COTV>(tp, nwg, ntaps, stream)                       \
+                          : launch_tap<float, CINV, COTV>(tp, nwg, ntaps, stream);
+
+static int dispatch_tap(const WTapParams& tp, int dtype, int cin, int cot, int nwg, int ntaps, hipStream_t stream) {
+    WT_CASE(16, 1) WT_CASE(16, 2) WT_CASE(16, 3) WT_CASE(16, 5) WT_CASE(16, 8)
+    WT_CASE(64, 1) WT_CASE(64, 4)
+    WT_CASE(128, 1) WT_CASE(128, 2) WT_CASE(128, 4) WT_CASE(128, 8)
+    return ERF_EUNSUPPORTED;
+}
+
+// All phases and taps in one launch, one workspace slice per phase; the per-phase reductions follow (or are recorded).
+static int wgrad_tap_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, int cot, int cin, int max_taps,
+                            const PackParams* maps, float* dw, float* workspace, size_t workspace_bytes, int dtype,
+                            hipStream_t stream) {
+    const long long P = (long long)geo.N * geo.Hb * geo.Wb;
+    const int rows_pad = cot * 16;
+    int nwg, ppw;
+    tap_plan(P, (size_t)rows_pad * max_taps * cin * sizeof(float), max_taps, &nwg, &ppw);
+    const size_t per_phase = (size_t)nwg * rows_pad * max_taps * cin * sizeof(float);
+    if (per_phase * geo.nphase > workspace_bytes) return ERF_EUNSUPPORTED;
+    if (dzoff + rows_pad > lddz) return ERF_EUNSUPPORTED;      // a pixel's row chunks are read whole
+    WTapParams tp{};
+    tp.x = geo.x; tp.dz = dz;
+    tp.N = geo.N; tp.Hin = geo.Hin; tp.Win = geo.Win; tp.ldx = geo.ldx; tp.xoff = geo.xoff; tp.Hb = geo.Hb; tp.Wb = geo.Wb;
+    tp.Hout = geo.Hout; tp.Wout = geo.Wout; tp.lddz = lddz; tp.dzoff = dzoff; tp.Si = geo.Si; tp.So = geo.So;
+    tp.P = (unsigned)P; tp.ppw = ppw; tp.rows_pad = rows_pad;
+    tp.fW = make_fastdiv((uint32_t)geo.Wb); tp.fH = make_fastdiv((uint32_t)geo.Hb);
+    int ntaps = 0;
+    for (int ph = 0; ph < geo.nphase; ++ph) {
+        const GConvPhase& g = geo.ph[ph];
+        for (int t = 0; t < g.ntaps; ++t) {
+            if (ntaps >= GC_MAX_TAPS) return ERF_EUNSUPPORTED;
+            WTapEntry& e = tp.e[ntaps++];
+            e.partial = workspace + (per_phase / sizeof(float)) * ph;
+            e.oh = g.oh; e.ow = g.ow; e.dh = g.dh[t]; e.dw = g.dw[t]; e.col0 = t * cin; e.ncols_pad = g.ntaps * cin;
+        }
+    }
+    int rc = dispatch_tap(tp, dtype, cin, cot, nwg, ntaps, stream);
+    if (rc) return rc;
+    for (int ph = 0; ph < geo.nphase; ++ph) {
+        rc = wgrad_reduce_launch(workspace + (per_phase / sizeof(float)) * ph, nwg, rows_pad, geo.ph[ph].ntaps * cin, cin, maps[ph],
+                                 dw, stream);
+        if (rc) return rc;
+    }
+    return ERF_OK;
+}
+
 int wgrad_launch(const GConvParams& geo, const void* dz, int lddz, int dzoff, int rows, int cin, const PackParams* maps,
                  float* dw, float* workspace, size_t workspace_bytes, int dtype, hipStream_t stream) {
     const long long P = (long long)geo.N * geo.Hb * geo.Wb;
     const int cot = (rows + 15) / 16;
     int max_taps = 1;
     for (int ph = 0; ph < geo.nphase; ++ph) max_taps = geo.ph[ph].ntaps > max_taps ? geo.ph[ph].ntaps : max_taps;
-    int nwg, spw;                       // same plan as wgrad_workspace_bytes (the caller sized the workspace with it)
-    plan(P, (size_t)cot * 16 * ((max_taps * cin + 15) / 16 * 16) * sizeof(float), &nwg, &spw);
     const int epc = dtype == 1 ? 8 : 4;
     if (cin % epc) return ERF_EUNSUPPORTED;
+    if (tap_path(rows, cin, P)) {
+        const int rc = wgrad_tap_launch(geo, dz, lddz, dzoff, cot, cin, max_taps, maps, dw, workspace, workspace_bytes, dtype, stream);
+        if (rc != ERF_EUNSUPPORTED) return rc;
+    }
+    int nwg, spw;                       // same plan as wgrad_workspace_bytes (the caller sized the workspace with it)
+    plan(P, (size_t)cot * 16 * ((max_taps * cin + 15) / 16 * 16) * sizeof(float), &nwg, &spw);
     // phases get a workspace slice each when the caller left room for that (their reductions can then be put off);
     // with one shared workspace a phase's partial tiles must be reduced before the next phase overwrites them
     const size_t per_phase = (size_t)nwg * cot * 16 * ((max_taps * cin + 15) / 16 * 16) * sizeof(float);
