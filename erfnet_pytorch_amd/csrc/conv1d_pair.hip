@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 typedef bf16raw T;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct PairParams {
     const T* x;
@@ -521,6 +522,253 @@ void conv1d_pair_kernel(const PairParams p) {
 #endif
 }
 
+// ---- Producer / consumer form for 128 channels -------------------------------------------------------------------------
+// In conv1d_pair_kernel every wave of the one workgroup a CU holds owns 16 output channels of BOTH convolutions and all
+// waves walk the phases of a tile in lockstep: every 1 KB pixel-fragment read feeds a single matrix instruction, and
+// nothing runs under the epilogue / read-back / store half of a tile.  Here the eight waves split by ROLE:
+//   waves 0-3 (producers) hold the 3x1 weights, 32 output channels each: DMA of tile s+1, GEMM 1 of tile s -> intermediate
+//                         rows in LDS (two buffers);
+//   waves 4-7 (consumers) hold the 1x3 weights, 32 output channels each: GEMM 2 of tile s-1 from the other intermediate
+//                         buffer, scale/shift (+ residual) and the stores straight from the accumulators (a lane owns
+//                         4 consecutive channels of a pixel: 8-byte pieces, 64 contiguous bytes per pixel and wave).
+// A SIMD runs one wave of each role, so one role's matrix instructions cover the other's reads, epilogue and stores;
+// every fragment read feeds two matrix instructions; a stage has ONE workgroup barrier (the hand-over of the intermediate
+// and of the freshly landed input tile).  The sums are those of conv1d_pair_kernel, K-step for K-step: bit-identical.
+template <int C, int R, int TC, bool POST>
+__global__ __launch_bounds__(512, 1)
+void conv1d_pair_pc_kernel(const PairParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int CH = C / 8;
+    constexpr int PIXB = C * 2;
+    constexpr int NP = 4;                              // waves per role
+    constexpr int CTW = (C / 16) / NP;
+    constexpr int M = R * TC, PTW = M / 16;
+    constexpr int KS = (3 * CH + 3) / 4;
+    constexpr int RS = TC + 2;
+    constexpr int INB = (R + 2) * TC * PIXB;           // one input buffer
+    constexpr int KIP = INB / (NP * 1024);             // DMA slots per producer lane
+    constexpr int MIDB = R * RS * PIXB;                // one intermediate buffer
+    constexpr int NCL = (CH < 16 ? CH : 16) / 4;
+    static_assert(CH >= 16 && CH % 4 == 0 && TC == 16 && (C / 16) % NP == 0 && KIP * NP * 1024 == INB, "producer/consumer tiling");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MID = 2 * INB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave / NP, wn = wave % NP;
+    const int q = lane >> 4, r16 = lane & 15;
+
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((const char*)p.x - p.pad, p.bytes + p.pad);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y, p.bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.res ? p.res : p.x, p.bytes);
+
+    i32x4 w[CTW][KS];
+    f32x4 sc[CTW], sh[CTW];
+    {
+        const i32x4* pw = (const i32x4*)(role ? p.wB : p.wA);
+        const float* ps = role ? p.scaleB : p.scaleA;
+        const float* pt = role ? p.shiftB : p.shiftA;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[c][ks] = pw[((wn * CTW + c) * KS + ks) * 64 + lane];
+            const int co = (wn * CTW + c) * 16 + q * 4;
+            sc[c] = ps ? *(const f32x4*)(ps + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+            sh[c] = pt ? *(const f32x4*)(pt + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) tie_reg(w[c][ks]);
+        asm volatile("" : "+v"(sc[c]), "+v"(sh[c]));
+    }
+
+    // both intermediate buffers start as zeros; only slots 1..TC of each row are ever written
+    for (int o = tid * 16; o < 2 * MIDB; o += 512 * 16) *(i32x4*)(smem + MID + o) = i32x4{0, 0, 0, 0};
+
+    int tile = blockIdx.x, tile_end = p.ntiles, G = gridDim.x;
+    if ((G & 7) == 0) {                                // one contiguous eighth of the tile sequence per XCD (see above)
+        const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        tile = xcd * per + (blockIdx.x >> 3);
+        tile_end = (xcd + 1) * per < p.ntiles ? (xcd + 1) * per : p.ntiles;
+        G >>= 3;
+    }
+    const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ producers
+        uint32_t in_rel[KIP];
+        int in_uj[KIP];
+#pragma unroll
+        for (int k = 0; k < KIP; ++k) {
+            const int id = (k * NP + wn) * 64 + lane;
+            const int pix = id / CH, slot = id % CH;
+            const int u = pix / TC, j = pix % TC;
+            in_rel[k] = (uint32_t)((u * p.W + j) * p.d) * PIXB + swz<PIXB>(pix, slot) * 16;
+            in_uj[k] = (u << 16) | j;
+        }
+        int lb1[NCL], mid_w[CTW];
+#pragma unroll
+        for (int cl = 0; cl < NCL; ++cl) lb1[cl] = r16 * PIXB + swz<PIXB>(r16, cl * 4 + q) * 16;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+            const int chunk = (wn * CTW + c) * 2 + (q >> 1);
+            mid_w[c] = MID + (r16 + 1) * PIXB + swz<PIXB>(r16 + 1, chunk) * 16 + (q & 1) * 8;
+        }
+#pragma unroll
+        for (int k = 0; k < KIP; ++k) asm volatile("" : "+v"(in_rel[k]), "+v"(in_uj[k]));
+#pragma unroll
+        for (int i = 0; i < NCL; ++i) asm volatile("" : "+v"(lb1[i]));
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) asm volatile("" : "+v"(mid_w[c]));
+
+        PairGeo g = pair_geo<C, R, TC>(p, tile, tile_end);
+        pair_dma<KIP, NP>(rs_x, smem, in_rel, in_uj, g, wn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ERF_LDS_BARRIER();                             // tile 0 has landed, the intermediate buffers are cleared
+        for (int cur = 0;; tile += G, cur ^= 1) {
+            const bool active = tile < tile_end;
+            if (active) {
+                const PairGeo gn = pair_geo<C, R, TC>(p, tile + G, tile_end);
+                pair_dma<KIP, NP>(rs_x, smem + (cur ^ 1) * INB, in_rel, in_uj, gn, wn);
+                int lb[NCL];
+#pragma unroll
+                for (int i = 0; i < NCL; ++i) lb[i] = lb1[i] + cur * INB;
+                const int moff = cur * MIDB;
+                f32x4 acc[PTW][CTW];
+                auto ep1 = [&](auto pti) {
+                    constexpr int pt = decltype(pti)::value;
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c) {
+                        f32x4 v = acc[pt][c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[c][e] + sh[c][e], 0.f);
+                        *(i32x2*)(smem + moff + mid_w[c] + pt * RS * PIXB) = pack_bf16x4(v);
+                    }
+                };
+                mfma_phase_shared<C, TC, PTW, CTW>(lb, w, acc, ep1);
+                if (g.jhi < TC) {                      // intermediate pixels right of the image are the 1x3 zero padding
+                    if (r16 >= g.jhi) {
+#pragma unroll
+                        for (int pt = 0; pt < PTW; ++pt)
+#pragma unroll
+                            for (int c = 0; c < CTW; ++c) *(i32x2*)(smem + moff + mid_w[c] + pt * RS * PIXB) = i32x2{0, 0};
+                    }
+                }
+                g = gn;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the next tile has landed
+            }
+            ERF_LDS_BARRIER();
+            if (!active) break;
+        }
+    } else {
+        // ------------------------------------------------------------------ consumers
+        int lb2[3 * NCL];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int cl = 0; cl < NCL; ++cl) lb2[tap * NCL + cl] = MID + (r16 + tap) * PIXB + swz<PIXB>(r16 + tap, cl * 4 + q) * 16;
+        uint32_t orel[CTW];
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) orel[c] = (uint32_t)(r16 * p.d) * PIXB + ((wn * CTW + c) * 16 + q * 4) * 2;
+#pragma unroll
+        for (int i = 0; i < 3 * NCL; ++i) asm volatile("" : "+v"(lb2[i]));
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) asm volatile("" : "+v"(orel[c]));
+        const uint32_t rowb = (uint32_t)(p.W * p.d) * PIXB;           // one lattice row down
+
+        ERF_LDS_BARRIER();
+        const int tile0 = tile;
+        for (int cur = 0;; tile += G, cur ^= 1) {
+            const bool active = tile < tile_end;
+            if (tile != tile0) {                       // GEMM 2 of the tile the producers finished in the previous stage
+                const PairGeo g = pair_geo<C, R, TC>(p, tile - G, tile_end);
+                uint32_t vo[CTW];
+                const bool colok = r16 >= g.jlo && r16 < g.jho;
+#pragma unroll
+                for (int c = 0; c < CTW; ++c) vo[c] = colok ? orel[c] : ERF_OOB;
+                i32x2 rv[PTW][CTW];
+                if constexpr (POST) {
+#pragma unroll
+                    for (int pt = 0; pt < PTW; ++pt)
+#pragma unroll
+                        for (int c = 0; c < CTW; ++c)
+                            rv[pt][c] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, pt < g.ihi ? vo[c] : ERF_OOB,
+                                                                                                       g.out_soff + pt * rowb, 0));
+                }
+                int lb[3 * NCL];
+#pragma unroll
+                for (int i = 0; i < 3 * NCL; ++i) lb[i] = lb2[i] + (cur ^ 1) * MIDB;
+                f32x4 acc[PTW][CTW];
+                auto ep2 = [&](auto pti) {
+                    constexpr int pt = decltype(pti)::value;
+                    if constexpr (POST && pt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the residual pieces
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c) {
+                        f32x4 v = acc[pt][c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = v[e] * sc[c][e] + sh[c][e];
+                            if constexpr (!POST) v[e] = fmaxf(v[e], floor_v);
+                        }
+                        i32x2 o = pack_bf16x4(v);
+                        if constexpr (POST) {          // same rounding points as the staged epilogue: bf16, + residual, bf16
+                            f32x4 f, r;
+                            f[0] = __uint_as_float(((uint32_t)o[0]) << 16); f[1] = __uint_as_float(((uint32_t)o[0]) & 0xFFFF0000u);
+                            f[2] = __uint_as_float(((uint32_t)o[1]) << 16); f[3] = __uint_as_float(((uint32_t)o[1]) & 0xFFFF0000u);
+                            const i32x2 rr = rv[pt][c];
+                            r[0] = __uint_as_float(((uint32_t)rr[0]) << 16); r[1] = __uint_as_float(((uint32_t)rr[0]) & 0xFFFF0000u);
+                            r[2] = __uint_as_float(((uint32_t)rr[1]) << 16); r[3] = __uint_as_float(((uint32_t)rr[1]) & 0xFFFF0000u);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) f[e] = fmaxf(f[e] + r[e], floor_v);
+                            o = pack_bf16x4(f);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_y, pt < g.ihi ? vo[c] : ERF_OOB,
+                                                              g.out_soff + pt * rowb, 0);
+                    }
+                    // the data registers of a buffer store with an SGPR offset must not be rewritten right after its issue
+                    asm volatile("s_nop 4" ::: "memory");
+                };
+                mfma_phase<C, TC, PTW, CTW, ImmMid>(lb, w, acc, q, ep2);
+            }
+            ERF_LDS_BARRIER();
+            if (!active) break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
+#endif
+}
+
+template <int C, int R, int TC>
+static int launch_pair_pc(PairParams p, hipStream_t stream) {
+    constexpr int PIXB = C * 2;
+    constexpr size_t lds = 2 * (size_t)(R + 2) * TC * PIXB + 2 * (size_t)R * (TC + 2) * PIXB;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    const int nh = (p.H + p.d - 1) / p.d, nw = (p.W + p.d - 1) / p.d;
+    p.CA = (nh + R - 1) / R;
+    p.CB = nw <= 2 ? 1 : (nw - 2 + TC - 3) / (TC - 2);
+    const long long nt = (long long)p.N * p.d * p.d * p.CA * p.CB;
+    if (nt > 0x1FFFFFFF) return ERF_EUNSUPPORTED;
+    p.ntiles = (int)nt;
+    p.fCB = make_fastdiv(p.CB); p.fCA = make_fastdiv(p.CA); p.fD = make_fastdiv(p.d);
+    const long long bytes = (long long)p.N * p.H * p.W * PIXB, pad = (long long)p.d * p.W * PIXB;
+    if (bytes + pad + (long long)(R + 2) * pad >= 0x7FFFFFFFLL) return ERF_EUNSUPPORTED;
+    p.bytes = (uint32_t)bytes; p.pad = (uint32_t)pad;
+    const int grid = 256 < p.ntiles ? 256 : p.ntiles;
+    if (p.res) {
+        auto kern = conv1d_pair_pc_kernel<C, R, TC, true>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ERF_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    } else {
+        auto kern = conv1d_pair_pc_kernel<C, R, TC, false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ERF_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    }
+    return erf_check_launch();
+}
+
 template <int C, int WM, int WN, int M, int TC, int KI, int OCC, bool POST>
 static void launch_kernel(size_t lds, int grid, hipStream_t stream, const PairParams& p) {
     auto kern = conv1d_pair_kernel<C, WM, WN, M, TC, KI, OCC, POST>;
@@ -578,6 +826,8 @@ int conv1d_pair_launch(const void* x, void* y, const void* packedA, const void* 
         const double u16 = pair_utilization(H, W, dilation, 8, 16), u32 = pair_utilization(H, W, dilation, 4, 32);
         if (u16 < 0.6 && u32 < 0.6) return ERF_EUNSUPPORTED;
         if (u32 > u16 * 1.1) return launch_pair<128, 1, 8, 128, 32, 6>(p, stream);
+        static const int pc_off = erf_debug_env("ERF_PAIR_PC_OFF", 0);
+        if (!pc_off) return launch_pair_pc<128, 8, 16>(p, stream);
         return launch_pair<128, 1, 8, 128, 16, 5>(p, stream);
     }
     if (C == 64) {
