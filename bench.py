@@ -202,7 +202,7 @@ def roofline_infer(model, x, dtype_name):
     torch.cuda.synchronize()
     # replayed from a HIP graph so that the events bracket back-to-back kernels, not host launch gaps
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (a process-group watchdog) may query events meanwhile
         run()
     graph.replay()
     torch.cuda.synchronize()
@@ -259,7 +259,7 @@ def run_infer(args, world, rank, dev, dtype=None, steps=None, warmup=None, roofl
     graph = None
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (a process-group watchdog) may query events meanwhile
             step()
         run = graph.replay
     else:
@@ -314,7 +314,7 @@ def run_multi(args, world, rank, dev):
     graph = None
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (a process-group watchdog) may query events meanwhile
             step()
     run = graph.replay if graph is not None else step
     for _ in range(args.warmup):

@@ -201,7 +201,7 @@ int argmax_launch(const void* z, int dtype, void* lab, int label_bytes, int N, i
 // Confusion-matrix histogram: per-workgroup nc x nc counters in LDS (atomics), flushed with one
 // global 64-bit atomic per non-zero cell.  Grid-stride, 8 pixels per thread per trip.
 template <typename TP, typename TLB>
-__global__ __launch_bounds__(256) void iou_hist_kernel(const TP* __restrict__ pred, const TLB* __restrict__ label,
+__global__ __launch_bounds__(1024) void iou_hist_kernel(const TP* __restrict__ pred, const TLB* __restrict__ label,
                                                        long long count, int nc, unsigned long long* __restrict__ hist) {
     // one private copy of the counters per wave (less contention on the LDS atomics); a thread takes 8 consecutive
     // pixels per trip (vector loads) and merges runs of equal (label, prediction) pairs before touching LDS --
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void iou_hist_kernel(const TP* __restrict__ pr
     const int cells = nc * nc + 1;
     for (int i = threadIdx.x; i < 4 * (32 * 32 + 1); i += blockDim.x) (&sh[0][0])[i] = 0;
     __syncthreads();
-    unsigned int* mine = sh[threadIdx.x >> 6];
+    unsigned int* mine = sh[(threadIdx.x >> 6) & 3];
     const long long groups = count >> 3;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; gidx < groups; gidx += stride) {
@@ -226,17 +226,23 @@ __global__ __launch_bounds__(256) void iou_hist_kernel(const TP* __restrict__ pr
 #pragma unroll
             for (int k = 0; k < 8; k += 2) *(i32x4*)(lv + k) = *(const i32x4*)(label + gidx * 8 + k);
         }
-        int prev = -1;
-        unsigned int run = 0;
+        // keys in 32-bit arithmetic (a 64-bit value is in range iff its high word is zero and its low word is below nc);
+        // equal neighbours are merged without branches: a pixel adds its run length when the next key differs
+        int key[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const long long g = (long long)lv[k], q = (long long)pv[k];
-            const int key = (g >= 0 && g < nc && q >= 0 && q < nc) ? (int)(g * nc + q) : nc * nc;
-            if (key == prev) { ++run; continue; }
-            if (run) atomicAdd(&mine[prev], run);
-            prev = key; run = 1;
+            const unsigned long long g = (unsigned long long)(long long)lv[k], q = (unsigned long long)(long long)pv[k];
+            const unsigned glo = (unsigned)g, qlo = (unsigned)q;
+            const bool ok = (unsigned)(g >> 32) == 0u && (unsigned)(q >> 32) == 0u && glo < (unsigned)nc && qlo < (unsigned)nc;
+            key[k] = ok ? (int)(glo * (unsigned)nc + qlo) : nc * nc;
         }
-        atomicAdd(&mine[prev], run);
+        unsigned int run = 1;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            if (key[k] != key[k + 1]) { atomicAdd(&mine[key[k]], run); run = 1; }
+            else ++run;
+        }
+        atomicAdd(&mine[key[7]], run);
     }
     // tail (count not a multiple of 8)
     for (long long i = groups * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
@@ -254,10 +260,12 @@ int iou_hist_launch(const void* pred, int pred_bytes, const void* label, int lab
                     long long* hist, hipStream_t stream) {
     if (nc < 1 || nc > 32 || count < 0) return ERF_EINVAL;
     if (count == 0) return ERF_OK;
-    long long blocks = (count + 256 * 8 * 4 - 1) / (256 * 8 * 4);
-    if (blocks > 1024) blocks = 1024;
+    // One workgroup of 16 waves per CU at most: every workgroup ends with one 64-bit global atomic per non-zero cell, and
+    // atomics on one address are served one after the other -- 1024 small workgroups spent most of the launch there.
+    long long blocks = (count + 1024 * 8 * 4 - 1) / (1024 * 8 * 4);
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-#define IH(TP, TLB) hipLaunchKernelGGL((iou_hist_kernel<TP, TLB>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TP*)pred, (const TLB*)label, count, nc, (unsigned long long*)hist)
+#define IH(TP, TLB) hipLaunchKernelGGL((iou_hist_kernel<TP, TLB>), dim3((unsigned)blocks), dim3(1024), 0, stream, (const TP*)pred, (const TLB*)label, count, nc, (unsigned long long*)hist)
     if (pred_bytes == 1 && label_bytes == 8) IH(unsigned char, long long);
     else if (pred_bytes == 8 && label_bytes == 8) IH(long long, long long);
     else if (pred_bytes == 1 && label_bytes == 1) IH(unsigned char, unsigned char);

@@ -14,7 +14,9 @@
 // STAGE (fp32 logits, Win a multiple of 16): a tile's 16 input pixels are 32 consecutive output columns of two rows; the
 // wave parks its logits in LDS as [class][row][32 columns] and writes them back as 16-byte pieces, 128 contiguous bytes
 // per (class, row), instead of one scattered 4-byte store per lane and class.
-template <typename T, int CT, int PT, bool STAGE>
+// LOGITS = false: labels only (the inference path) -- no per-class branches at all: classes beyond nc (last channel tile
+// only) are masked by a select, so a tile is ~150 straight-line instructions instead of ~90 wave-uniform branches.
+template <typename T, int CT, int PT, bool STAGE, bool LOGITS = true>
 __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, const i32x4* __restrict__ w,
                                                       const float* __restrict__ bias, void* __restrict__ logits,
                                                       int logits_mode, void* __restrict__ labels, int label_bytes, int N,
@@ -39,12 +41,19 @@ __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, c
 #pragma unroll
         for (int e = 0; e < 4; ++e) bs[c][e] = 4 * c + e < nc ? bias[4 * c + e] : 0.f;
 
+    // all PT pixel fragments are requested before the first is used (unconditional loads from clamped addresses, masked
+    // afterwards: a load under a branch would be waited for tile by tile)
+    i32x4 bq[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const unsigned pix = tile0 + t * 16 + r16;
+        bq[t] = *(const i32x4*)(x + (long long)(pix < P ? pix : 0) * 16 + (q < CH ? q : 0) * EPC);
+    }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         const unsigned pix = tile0 + t * 16 + r16;
         const bool pv = pix < P;
-        i32x4 b = {0, 0, 0, 0};
-        if (pv && q < CH) b = *(const i32x4*)(x + (long long)pix * 16 + q * EPC);
+        const i32x4 b = (pv && q < CH) ? bq[t] : i32x4{0, 0, 0, 0};
         f32x4 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[c] = mma_step<T>(a[c], b, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -63,7 +72,13 @@ __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int cls = 4 * c + e;
-                if (cls < nc) {                                  // wave-uniform
+                if constexpr (!LOGITS) {
+                    float val = acc[c][e] + bs[c][e];
+                    if (c == CT - 1 && e > 0) val = cls < nc ? val : -INFINITY;      // ct = ceil(nc / 4): only these can lie beyond nc
+                    const bool better = val > bv;                // first maximum wins, as torch.max(1)
+                    bv = better ? val : bv;
+                    bi = better ? cls : bi;
+                } else if (cls < nc) {                           // wave-uniform
                     const float val = acc[c][e] + bs[c][e];
                     if constexpr (STAGE) {
                         st[cls * 64 + (q >> 1) * 32 + 2 * r16 + (q & 1)] = val;
@@ -119,6 +134,9 @@ static int outconv_dispatch(int ct, dim3 grid, hipStream_t stream, const T* x, c
         if (logits_mode == 2 && (Win & 15) == 0)                                                                    \
             hipLaunchKernelGGL((outconv_kernel<T, CTV, 4, true>), grid, dim3(256), 0, stream, x, w, bias, logits,       \
                                logits_mode, labels, label_bytes, N, Hin, Win, nc, fW, fH);                              \
+        else if (logits_mode == 0)                                                                                  \
+            hipLaunchKernelGGL((outconv_kernel<T, CTV, 4, false, false>), grid, dim3(256), 0, stream, x, w, bias,       \
+                               logits, logits_mode, labels, label_bytes, N, Hin, Win, nc, fW, fH);                      \
         else                                                                                                        \
             hipLaunchKernelGGL((outconv_kernel<T, CTV, 4, false>), grid, dim3(256), 0, stream, x, w, bias, logits,      \
                                logits_mode, labels, label_bytes, N, Hin, Win, nc, fW, fH);                              \

@@ -256,7 +256,10 @@ class Trainer:
         graph = torch.cuda.CUDAGraph()
         # everything the step changed on the HOST during capture is undone below: the capture launches nothing
         host = (self._step_host, self._epoch[0])
-        with torch.cuda.graph(graph):                                 # anything that cannot be captured raises here
+        # thread_local: only this thread is held to the capture rules.  With the default (global) mode an event query by
+        # another thread while the capture is open -- the process group's watchdog polling the work of an earlier step --
+        # fails with "operation not permitted when stream is capturing" and takes the process down.
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # anything that cannot be captured raises here
             loss, outputs = self._step_eager(gx, gt)
         self._step_host, self._epoch[0] = host
         entry = (graph, gx, gt, loss, outputs)
