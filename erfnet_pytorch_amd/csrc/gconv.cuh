@@ -97,28 +97,39 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvParams p) {
     const int nchunks = ph.ntaps * CH;
     const int KS = ph.ksteps;
 
-    for (int ks = 0; ks < KS; ++ks) {
-        const int g = ks * 4 + q;
-        const bool gv = g < nchunks;
-        const int tap = gv ? g / CH : 0;
-        const int chunk = g % CH;
-        const int dh = s_dh[tap], dw = s_dw[tap];
-        i32x4 b[PT];
+    // The gathers are unconditional (masked lanes read pixel 0 and are zeroed afterwards) and two K-steps are taken per
+    // trip, so that their requests are in flight together instead of one memory round trip per step.
+    constexpr int U = 2;
+    for (int ks0 = 0; ks0 < KS; ks0 += U) {
+        i32x4 b[U][PT], a[U][CT];
+        bool ok[U][PT];
 #pragma unroll
-        for (int t = 0; t < PT; ++t) {
-            const int hi = pi[t] * p.Si + dh, wi = pj[t] * p.Si + dw;
-            const bool ok = gv && pv[t] && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-            b[t] = i32x4{0, 0, 0, 0};
-            if (ok) {
-                const long long off = (((long long)pn[t] * p.Hin + hi) * p.Win + wi) * p.ldx + chunk * EPC;
-                b[t] = *(const i32x4*)(xb + off);
+        for (int u = 0; u < U; ++u) {
+            const int ks = ks0 + u;
+            const int g = ks * 4 + q;
+            const bool gv = ks < KS && g < nchunks;
+            const int tap = gv ? g / CH : 0;
+            const int chunk = g % CH;
+            const int dh = s_dh[tap], dw = s_dw[tap];
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const int hi = pi[t] * p.Si + dh, wi = pj[t] * p.Si + dw;
+                ok[u][t] = gv && pv[t] && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+                const long long off = ok[u][t] ? (((long long)pn[t] * p.Hin + hi) * p.Win + wi) * p.ldx + chunk * EPC : 0;
+                b[u][t] = *(const i32x4*)(xb + off);
             }
+            const int ksc = ks < KS ? ks : KS - 1;               // the odd tail re-reads the last step's weights (its pixels are zero)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) a[u][c] = wbase[((long long)c * KS + ksc) * 64 + lane];
         }
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const i32x4 a = wbase[((long long)c * KS + ks) * 64 + lane];
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int t = 0; t < PT; ++t) acc[c][t] = mma_step<T>(a, b[t], acc[c][t]);
+            for (int t = 0; t < PT; ++t) b[u][t] = ok[u][t] ? b[u][t] : i32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[c][t] = mma_step<T>(a[u][c], b[u][t], acc[c][t]);
         }
     }
 
