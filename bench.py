@@ -165,7 +165,8 @@ def roofline_infer(model, x, dtype_name):
     n, _, h, w = x.shape
     if dtype_name == "bf16":
         hh, ww, c = h // 4, w // 4, 64
-        feat = torch.randn(n, hh, ww, c, device=x.device).to(torch.bfloat16)
+        # block inputs are ReLU outputs in the network (about half zeros): the probe tensor has the same statistics
+        feat = torch.relu(torch.randn(n, hh, ww, c, device=x.device)).to(torch.bfloat16)
         mid, out = torch.empty_like(feat), torch.empty_like(feat)
         blocks = [m for m in list(model.encoder.layers) + list(model.decoder.layers) if getattr(m, "chann", 0) == 64]
         plan = []
