@@ -596,6 +596,16 @@ void conv1d_pair_pc_kernel(const PairParams p) {
         G >>= 3;
     }
     const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
+#ifdef ERF_DEBUG
+    // diagnostic build only (ERF_PAIR_DBG & 256): shader cycles per section of a stage, summed over this wave's stages,
+    // written over the head of y (scripts/pair_pc_phase_time.py reads them)
+    uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t tentry = __builtin_amdgcn_s_memtime();
+    uint64_t tprev = tentry;
+#define PC_STAMP(i) { const uint64_t tn = __builtin_amdgcn_s_memtime(); st[i] += tn - tprev; tprev = tn; }
+#else
+#define PC_STAMP(i)
+#endif
 
     if (role == 0) {
         // ------------------------------------------------------------------ producers
@@ -628,11 +638,13 @@ void conv1d_pair_pc_kernel(const PairParams p) {
         pair_dma<KIP, NP>(rs_x, smem, in_rel, in_uj, g, wn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ERF_LDS_BARRIER();                             // tile 0 has landed, the intermediate buffers are cleared
+        PC_STAMP(7)
         for (int cur = 0;; tile += G, cur ^= 1) {
             const bool active = tile < tile_end;
             if (active) {
                 const PairGeo gn = pair_geo<C, R, TC>(p, tile + G, tile_end);
                 pair_dma<KIP, NP>(rs_x, smem + (cur ^ 1) * INB, in_rel, in_uj, gn, wn);
+                PC_STAMP(0)
                 int lb[NCL];
 #pragma unroll
                 for (int i = 0; i < NCL; ++i) lb[i] = lb1[i] + cur * INB;
@@ -658,9 +670,12 @@ void conv1d_pair_pc_kernel(const PairParams p) {
                     }
                 }
                 g = gn;
+                PC_STAMP(1)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the next tile has landed
+                PC_STAMP(2)
             }
             ERF_LDS_BARRIER();
+            PC_STAMP(3)
             if (!active) break;
         }
     } else {
@@ -680,6 +695,7 @@ void conv1d_pair_pc_kernel(const PairParams p) {
         const uint32_t rowb = (uint32_t)(p.W * p.d) * PIXB;           // one lattice row down
 
         ERF_LDS_BARRIER();
+        PC_STAMP(7)
         const int tile0 = tile;
         for (int cur = 0;; tile += G, cur ^= 1) {
             const bool active = tile < tile_end;
@@ -698,6 +714,7 @@ void conv1d_pair_pc_kernel(const PairParams p) {
                             rv[pt][c] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_r, pt < g.ihi ? vo[c] : ERF_OOB,
                                                                                                        g.out_soff + pt * rowb, 0));
                 }
+                PC_STAMP(0)
                 int lb[3 * NCL];
 #pragma unroll
                 for (int i = 0; i < 3 * NCL; ++i) lb[i] = lb2[i] + (cur ^ 1) * MIDB;
@@ -732,12 +749,23 @@ void conv1d_pair_pc_kernel(const PairParams p) {
                     asm volatile("s_nop 4" ::: "memory");
                 };
                 mfma_phase<C, TC, PTW, CTW, ImmMid>(lb, w, acc, q, ep2);
+                PC_STAMP(1)
             }
             ERF_LDS_BARRIER();
+            PC_STAMP(3)
             if (!active) break;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
+#ifdef ERF_DEBUG
+    if ((p.dbg & 256) && lane == 0) {
+        uint64_t* o = (uint64_t*)p.y + (blockIdx.x * 8 + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = __builtin_amdgcn_s_memtime() - tentry;
+        o[9] = 0;
+    }
+#endif
+#undef PC_STAMP
 #endif
 }
 
