@@ -784,6 +784,54 @@ def erfnet_forward_loss(net, x, target, weight=None, group=None):
     return _HeadLossFn.apply(y, oc.weight, oc.bias, target, weight, group, oc)
 
 
+# ---- the same step cut at its two exchange points (a step replayed from HIP graphs with the collectives issued between them)
+def erfnet_forward_sums(net, x, target, weight=None):
+    """First part of erfnet_forward_loss: the decoder's features (autograd graph attached) and this rank's
+    (sum w*nll, sum w, ratio) of the fused output layer + loss, with NO exchange: the caller all-reduces the first two numbers.
+    Returns (features, sums, state for erfnet_backward_from_sums)."""
+    feats = encoder_forward(net.encoder, x, code=_compute_code(net, x))
+    y = feats
+    for layer in net.decoder.layers:
+        y = block_forward(layer, y)
+    oc = net.decoder.output_conv
+    w, b = oc.weight, oc.bias
+    xh = ops.to_nhwc(y.detach())
+    code, dev = ops.dt(xh), xh.device
+    n, h, wd, _ = xh.shape
+    nc = w.shape[1]
+    target = target.contiguous()
+    if target.dtype != torch.int64 or tuple(target.shape) != (n, 2 * h, 2 * wd):
+        raise ValueError(f"expected int64 targets of shape {(n, 2 * h, 2 * wd)}, got {target.dtype} {tuple(target.shape)}")
+    wt = None if weight is None else weight.detach().to(dev, torch.float32).contiguous()
+    packed = ops.packed_generic(oc, "fwd", w, code, lambda: ops.pack_output_conv(w, code))
+    bias = _f32(b)
+    out3 = torch.empty(3, device=dev)
+    ws = _ws(size_query("erf_output_conv_ce_workspace_bytes", n, h, wd), dev)
+    call("erf_output_conv_ce_fwd", xh.data_ptr(), packed.data_ptr(), bias.data_ptr(), target.data_ptr(), _p(wt), out3.data_ptr(),
+         ws.data_ptr(), code, n, h, wd, nc, _stream())
+    return y, out3, (xh, w, bias, target, wt, packed, oc)
+
+
+def erfnet_backward_from_sums(y, sums, state):
+    """Second part: loss = sums[0] / sums[1] (the caller has summed both over the ranks) and the whole backward pass, the
+    output layer's by hand with the coefficient 1 / sums[1] that _HeadLossFn.backward derives from a unit loss gradient."""
+    xh, w, bias, target, wt, packed, oc = state
+    code, dev = ops.dt(xh), xh.device
+    n, h, wd, _ = xh.shape
+    nc = w.shape[1]
+    den = sums[1].reshape(1)
+    loss = sums[0] / sums[1]
+    coef = (torch.ones(1, device=dev) / den).contiguous()
+    patches = torch.empty((n, h, wd, size_query("erf_output_conv_patch_channels", nc)), dtype=xh.dtype, device=dev)
+    call("erf_output_conv_ce_bwd", xh.data_ptr(), packed.data_ptr(), bias.data_ptr(), target.data_ptr(), _p(wt),
+         coef.data_ptr(), patches.data_ptr(), code, n, h, wd, nc, _stream())
+    grads = _outconv_backward(oc, xh, w, patches)
+    if grads[1] is not None:                             # no gradient arena attached: hand the output layer's gradients over
+        oc.weight.grad, oc.bias.grad = grads[1], grads[2]
+    y.backward(grads[0])
+    return loss
+
+
 def erfnet_forward(net, x):
     feats = encoder_forward(net.encoder, x, code=_compute_code(net, x))
     return decoder_forward(net.decoder, feats, logits_f32=x.dtype == torch.float32)

@@ -77,6 +77,24 @@ def _refresh_bank(bank, model, images):
     return bank
 
 
+class _NoCollection:
+    """No cyclic garbage collection while a capture is open: a collection that happens to free an older CUDAGraph object
+    (a discarded Trainer's, say) destroys that graph in the middle of the capture, which HIP refuses ("operation not
+    permitted when stream is capturing") -- from a destructor, i.e. the process aborts."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class Trainer:
     def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
                  group=None, world_size=1, overlap=True, only_encode=False, fused_head_loss=True, force_collectives=False,
@@ -88,7 +106,9 @@ class Trainer:
         group exercises the whole collective path -- hooks, side-stream ordering, waits -- on a single GPU).
         `graph`: step() captures the whole optimisation step (zero_grad .. Adam, collectives included) into a HIP graph
         the second time it sees an input shape and replays it from then on; the inputs are copied into the graph's
-        static buffers.  Everything that changes from step to step lives on the device for this (dropout seed counter,
+        static buffers.  graph="segments": the step is cut at its two exchange points into three graphs (forward + local
+        loss sums | backward | Adam) and the loss and gradient all-reduces are issued between the replays like any
+        other collective -- no collective is ever captured, and the host still enqueues three launches instead of ~370.  Everything that changes from step to step lives on the device for this (dropout seed counter,
         Adam's step count and learning rate), graph or not, so both ways of running give the same bits."""
         self.model = model
         self.only_encode = only_encode
@@ -144,6 +164,7 @@ class Trainer:
         self._lr_on_dev = float(lr)
         self._hyper = torch.zeros(2, dtype=torch.float32, device=dev)
         self.use_graph = bool(graph)
+        self.segments = graph == "segments" and self.collective and self.fused_head_loss
         self._graphs = {}                               # input signature -> (graph, static images, static targets, loss, outputs)
         self._seen = set()
         self._bank = None                               # packed factorized-conv weights, refreshed once per step
@@ -154,9 +175,9 @@ class Trainer:
         if self.overlap:
             last = len(self.buckets) - 1
             if not only_encode:
-                model.decoder.layers[0].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(0)
-            model.encoder.layers[6].__dict__["_erf_after_backward"] = lambda: self._launch_bucket(last - 1)
-            model.encoder.initial_block.__dict__["_erf_after_backward"] = lambda: self._launch_bucket(last)
+                model.decoder.layers[0].__dict__["_erf_after_backward"] = lambda: self._bucket_hook(0)
+            model.encoder.layers[6].__dict__["_erf_after_backward"] = lambda: self._bucket_hook(last - 1)
+            model.encoder.initial_block.__dict__["_erf_after_backward"] = lambda: self._bucket_hook(last)
 
     # -- Adam's step count: the device copy is what the kernels read, the host copy mirrors it --------
     @property
@@ -175,6 +196,10 @@ class Trainer:
             self._lr_on_dev = float(self.lr)
 
     # -- collectives ------------------------------------------------------------------------
+    def _bucket_hook(self, i):
+        if self.overlap:                                              # off while a backward pass is captured without collectives
+            self._launch_bucket(i)
+
     def _launch_bucket(self, i):
         import torch.distributed as dist
         lo, hi = self.buckets[i]
@@ -234,11 +259,21 @@ class Trainer:
             if key not in self._seen:                                 # first sight of a shape: run it eagerly (sizes caches, workspaces)
                 self._seen.add(key)
                 return self._step_eager(images, targets)
-            entry = self._capture(key, images, targets)
+            entry = self._capture_segments(key, images, targets) if self.segments else self._capture(key, images, targets)
         graph, gx, gt, loss, outputs = entry
         gx.copy_(images)
         gt.copy_(targets)
-        graph.replay()
+        if self.segments:
+            import torch.distributed as dist
+            g1, g2, g3, sums = graph
+            g1.replay()
+            dist.all_reduce(sums[:2], group=self.group)               # (sum w*nll, sum w) over the global batch
+            g2.replay()
+            for lo, hi in self.buckets:
+                dist.all_reduce(self.gflat[lo:hi], group=self.group)
+            g3.replay()
+        else:
+            graph.replay()
         self._after_replayed_step()
         return loss, outputs
 
@@ -259,10 +294,38 @@ class Trainer:
         # thread_local: only this thread is held to the capture rules.  With the default (global) mode an event query by
         # another thread while the capture is open -- the process group's watchdog polling the work of an earlier step --
         # fails with "operation not permitted when stream is capturing" and takes the process down.
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):      # anything that cannot be captured raises here
+        with _NoCollection(), torch.cuda.graph(graph, capture_error_mode="thread_local"):   # anything that cannot be captured raises here
             loss, outputs = self._step_eager(gx, gt)
         self._step_host, self._epoch[0] = host
         entry = (graph, gx, gt, loss, outputs)
+        self._graphs[key] = entry
+        return entry
+
+    def _capture_segments(self, key, images, targets):
+        """Three graphs around the two exchange points of a step; see __init__.  The capture itself launches nothing and
+        issues no collective (the first, eager, step of this shape has already run them once)."""
+        gx, gt = images.clone(), targets.clone()
+        torch.cuda.synchronize()
+        host = (self._step_host, self._epoch[0])
+        overlap, self.overlap = self.overlap, False                   # the bucket hooks stay silent: buckets go out between g2 and g3
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        try:
+            with _NoCollection():
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                    self.zero_grad()
+                    self._refresh_packed(gx)
+                    _prepare_masks(self.model, gx, self._seed_state)
+                    feats, sums, state = ag.erfnet_forward_sums(self.model, gx, gt, self.weight)
+                    _flush_batch_counters(self._counted)
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                    loss = ag.erfnet_backward_from_sums(feats, sums, state).detach()
+                    ag.flush_bias_sums()
+                with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode="thread_local"):
+                    self.optimizer_step()
+        finally:
+            self.overlap = overlap
+        self._step_host, self._epoch[0] = host
+        entry = ((g1, g2, g3, sums), gx, gt, loss, None)
         self._graphs[key] = entry
         return entry
 
@@ -441,9 +504,12 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else None
     group = dist.group.WORLD if world > 1 else None
-    # One GPU: the step is replayed from a HIP graph.  Several GPUs: kernel-by-kernel launches unless --train-graph asks for
-    # the capture (it includes the RCCL all-reduces; verified with a one-rank group only, and the step is GPU-bound either way).
-    use_graph = not getattr(args, "no_graph", False) and (world == 1 or getattr(args, "train_graph", False))
+    # One GPU: the step is replayed from one HIP graph.  Several GPUs: three graphs (forward | backward | Adam) with the loss and
+    # gradient all-reduces issued between the replays -- launched kernel by kernel the step is host-bound (6.5 ms against
+    # 5.4 ms of kernels); --train-graph captures the RCCL all-reduces into one graph instead (verified with a one-rank group only).
+    use_graph = False
+    if not getattr(args, "no_graph", False):
+        use_graph = True if (world == 1 or getattr(args, "train_graph", False)) else "segments"
     tr = Trainer(model, CITYSCAPES_WEIGHTS, group=group, world_size=world, graph=use_graph)
     torch.manual_seed(1234 + rank)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -477,7 +543,8 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"ERFNet(20) training step (fwd + weighted CE + bwd + RCCL grad all-reduce + Adam), batch {batch}/GPU, "
                                f"3x{args.height}x{args.width}, data parallel x{world}",
-                   "global_batch": batch * world, "final_loss": float(loss), "hip_graph": bool(tr._graphs)},
+                   "global_batch": batch * world, "final_loss": float(loss),
+                   "hip_graph": ("segments" if tr.segments else True) if tr._graphs else False},
         "model_tflops": value * flop_img / 1e12,
     }
 

@@ -57,6 +57,7 @@ def test_two_rank_line_reports_training_as_the_headline(tmp_path):
     assert BASE_KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert "training step" in d["config"]["workload"] and d["config"]["global_batch"] == 4
+    assert d["config"]["hip_graph"] == "segments"             # three graphs, the collectives between their replays
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert "REHEARSAL" in d["data"]
     inf = d["inference"]

@@ -39,7 +39,15 @@ def _shard(rank):
     return x, t
 
 
-def _worker(rank, world, store_file, dtype, overlap, q):
+def _worker_steps_launched(rank, world, store_file, dtype, overlap, q):
+    _worker(rank, world, store_file, dtype, overlap, q, graph=False, steps=3)
+
+
+def _worker_steps_segments(rank, world, store_file, dtype, overlap, q):
+    _worker(rank, world, store_file, dtype, overlap, q, graph="segments", steps=3)
+
+
+def _worker(rank, world, store_file, dtype, overlap, q, graph=False, steps=1):
     import torch.distributed as dist
     from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
     dist.init_process_group("gloo", init_method=f"file://{store_file}", rank=rank, world_size=world)
@@ -51,10 +59,12 @@ def _worker(rank, world, store_file, dtype, overlap, q):
     try:
         torch.cuda.set_device(0)
         m = _build(dtype)
-        tr = Trainer(m, CITYSCAPES_WEIGHTS, group=dist.group.WORLD, world_size=world, overlap=overlap)
+        tr = Trainer(m, CITYSCAPES_WEIGHTS, group=dist.group.WORLD, world_size=world, overlap=overlap, graph=graph)
         x, t = _shard(rank)
-        loss, _ = tr.step(x, t)
+        for _ in range(steps):
+            loss, _ = tr.step(x, t)
         torch.cuda.synchronize()
+        assert tr.segments == (graph == "segments") and bool(tr._graphs) == bool(graph)
         q.put((rank, float(loss), tr.gflat.cpu().numpy().copy(), tr.flat.cpu().numpy().copy()))
         dist.barrier()
     finally:
@@ -126,6 +136,10 @@ def _rccl_graph_worker(rank, world, store_file, dtype, overlap, q):
     _rccl_worker(rank, world, store_file, dtype, overlap, q, graph=True, steps=4)
 
 
+def _rccl_segments_worker(rank, world, store_file, dtype, overlap, q):
+    _rccl_worker(rank, world, store_file, dtype, overlap, q, graph="segments", steps=5)
+
+
 def _rccl_worker(rank, world, store_file, dtype, overlap, q, graph=False, steps=2):
     """One rank, backend nccl (= RCCL): the production collective path on a single GPU."""
     import torch.distributed as dist
@@ -138,14 +152,15 @@ def _rccl_worker(rank, world, store_file, dtype, overlap, q, graph=False, steps=
         res = []
         for group in (dist.group.WORLD, None):
             tr = Trainer(_build(dtype), CITYSCAPES_WEIGHTS, group=group, world_size=1, overlap=overlap, force_collectives=True,
-                         graph=graph and group is not None)
+                         graph=graph if group is not None else False)
             assert tr.collective == (group is not None) and tr.overlap == (overlap and group is not None)
             losses = []
             for _ in range(steps):
                 loss, _ = tr.step(x, t)
                 losses.append(float(loss))
             torch.cuda.synchronize()
-            assert bool(tr._graphs) == (graph and group is not None)
+            assert bool(tr._graphs) == bool(graph and group is not None)
+            assert tr.segments == (graph == "segments" and group is not None)
             res.append((losses, tr.gflat.cpu().numpy().copy(), tr.flat.cpu().numpy().copy()))
         q.put((0, res))
         dist.barrier()
@@ -173,3 +188,26 @@ def test_captured_step_with_rccl_collectives_is_bit_identical_to_the_launched_on
     (l_a, g_a, p_a), (l_b, g_b, p_b) = got[0][0]
     assert l_a == l_b
     assert np.array_equal(g_a, g_b) and np.array_equal(p_a, p_b)
+
+
+@pytest.mark.parametrize("dtype,overlap", [("bf16", True), ("fp32", False)])
+def test_step_in_three_graphs_with_rccl_collectives_between_them_is_bit_identical_to_the_launched_one(dtype, overlap, tmp_path):
+    """Trainer(graph="segments") over a one-rank RCCL group (what bench.py runs at N > 1): forward + local loss sums, backward and
+    Adam are three HIP graphs, the loss all-reduce and the gradient-bucket all-reduces are issued between their replays and are
+    never captured; five steps (three of them replays) must match the group-less, kernel-by-kernel run bit for bit."""
+    got = _run(1, dtype, overlap, tmp_path, worker=_rccl_segments_worker)
+    (l_a, g_a, p_a), (l_b, g_b, p_b) = got[0][0]
+    assert l_a == l_b
+    assert np.array_equal(g_a, g_b) and np.array_equal(p_a, p_b)
+
+
+def test_two_rank_step_in_three_graphs_equals_the_launched_two_rank_step(tmp_path):
+    """Two ranks (gloo rehearsal on one GPU), three optimisation steps each: Trainer(graph="segments") -- eager first step, capture,
+    one replay, collectives between the graphs -- against the kernel-by-kernel two-rank run: loss, reduced gradients and parameters
+    bit for bit on both ranks."""
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    seg = _run(2, "bf16", True, tmp_path / "a", worker=_worker_steps_segments)
+    ref = _run(2, "bf16", True, tmp_path / "b", worker=_worker_steps_launched)
+    for r in range(2):
+        assert seg[r][0] == ref[r][0]
+        assert np.array_equal(seg[r][1], ref[r][1]) and np.array_equal(seg[r][2], ref[r][2])
