@@ -14,7 +14,8 @@ N = 1, headline (`value`): BASELINE.json configs[1] -- ERFNet(20) inference, bat
     "cpu_baseline"   the oracle's fp32 forward, b=1, on this box's host cores (eval_forwardTime protocol).
 N > 1 (launched by torch.distributed.run, one rank per GPU), headline: the data-parallel TRAINING step of configs[2]
   -- batch 6 per GPU, weighted cross-entropy, Adam, gradient all-reduce over RCCL inside the timed region ("weak"
-  scaling: per-GPU work fixed).  "inference" then holds the inference leg (independent shards per rank: the path has
+  scaling: per-GPU work fixed); the step is replayed from three HIP graphs with the all-reduces issued between them
+  (`--train-graph`: one graph with the all-reduces captured, `--no-graph`: kernel-by-kernel launches).  "inference" then holds the inference leg (independent shards per rank: the path has
   no exchange step), "world_size" what the process group reports, and "allreduce" the time of each gradient bucket's
   all-reduce alone.
 `--mode train` / `--mode infer` force one leg as the headline at any N.  Rank 0 prints exactly one JSON line.
