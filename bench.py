@@ -202,20 +202,23 @@ def roofline_infer(model, x, dtype_name):
         name = "conv1d_dma_kernel<float,128> (factorized conv, 128-channel blocks)"
     run()
     torch.cuda.synchronize()
-    # replayed from a HIP graph so that the events bracket back-to-back kernels, not host launch gaps
+    # replayed from a HIP graph so that the events bracket back-to-back kernels, not host launch gaps; the graph holds the
+    # plan several times over, so that the gap between two graph launches is spread over as many kernels as in a real step
+    inner = 4
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (a process-group watchdog) may query events meanwhile
-        run()
+        for _ in range(inner):
+            run()
     graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
+    reps = 5
     e0.record()
     for _ in range(reps):
         graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * len(plan))
+    avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * inner * len(plan))
     if dtype_name == "bf16":
         achieved = bytes_per_launch / avg_s / 1e9
         traffic = measured_traffic("conv1d_pair_kernel<64,", n * hh * ww)
