@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void outconv_kernel(const T* __restrict__ x, c
                     const bool better = val > bv;                // first maximum wins, as torch.max(1)
                     bv = better ? val : bv;
                     bi = better ? cls : bi;
-                } else if (cls < nc) {                           // wave-uniform
+                } else if (cls <= 4 * (CT - 1) || cls < nc) {    // wave-uniform; folds at compile time except for the last tile's classes 1..3
                     const float val = acc[c][e] + bs[c][e];
                     if constexpr (STAGE) {
                         st[cls * 64 + (q >> 1) * 32 + 2 * r16 + (q & 1)] = val;
