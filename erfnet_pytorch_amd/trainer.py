@@ -433,13 +433,20 @@ class ArenaSGD:
     `.grad` is a view of it; with world_size > 1 the loss is the global-batch mean and the arena is summed
     over the ranks (RCCL) in one all-reduce before one fused SGD launch."""
 
-    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, group=None, world_size=1):
+    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, group=None, world_size=1, graph=False):
+        """`graph` (one GPU): from the third step with one input shape and learning rate on, the whole step is replayed from a
+        HIP graph (the step is launch-bound at 224x224).  The Dropout2d seed counter lives on the device in both modes, so
+        replayed and launched steps draw the same masks; the learning rate is a constant of the captured launch (a new
+        value is captured anew)."""
         self.model, self.lr, self.momentum, self.wd = model, lr, momentum, weight_decay
         self.group, self.world = group, world_size
         self.step_count = 0
         self._epoch = [0]
         named = list(model.named_parameters())
         dev = named[0][1].device
+        self.use_graph = bool(graph) and world_size == 1
+        self._graphs, self._seen = {}, set()
+        self._seed_state = ag.new_seed_state(dev)
         total = sum(p.numel() for _, p in named)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
         self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -473,9 +480,36 @@ class ArenaSGD:
             p.grad = v                                  # autograd accumulates in place into the arena
 
     def step(self, images, targets):
+        if not self.use_graph or self.step_count == 0:                # the first step of a run also initialises the momentum buffers
+            return self._step_eager(images, targets)
+        key = (tuple(images.shape), images.dtype, tuple(targets.shape), getattr(self.model, "compute_dtype", None), float(self.lr))
+        entry = self._graphs.get(key)
+        if entry is None:
+            if key not in self._seen:                                 # first sight: run it eagerly (sizes caches, workspaces)
+                self._seen.add(key)
+                return self._step_eager(images, targets)
+            gx, gt = images.clone(), targets.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            host = (self.step_count, self._epoch[0])
+            with _NoCollection(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                loss, outputs = self._step_eager(gx, gt)
+            self.step_count, self._epoch[0] = host
+            entry = self._graphs[key] = (graph, gx, gt, loss, outputs)
+        graph, gx, gt, loss, outputs = entry
+        gx.copy_(images)
+        gt.copy_(targets)
+        graph.replay()
+        from . import ops
+        self._epoch[0] += 1
+        self.step_count += 1
+        ops.bump_param_epoch()
+        return loss, outputs
+
+    def _step_eager(self, images, targets):
         self.zero_grad()
         self._bank = _refresh_bank(getattr(self, "_bank", None), self.model, images)
-        _prepare_masks(self.model, images)
+        _prepare_masks(self.model, images, self._seed_state)
         outputs = self.model(images)
         loss = weighted_cross_entropy(outputs, targets, None, self.group if self.world > 1 else None)
         loss.backward()
@@ -559,11 +593,12 @@ def bench_imagenet(args, world, rank, dev, barrier, max_over_ranks):
     S.load_synthetic(model)
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else None
-    tr = ArenaSGD(model, 0.1, 0.9, 1e-4, group=dist.group.WORLD if world > 1 else None, world_size=world)
+    tr = ArenaSGD(model, 0.1, 0.9, 1e-4, group=dist.group.WORLD if world > 1 else None, world_size=world,
+                  graph=not getattr(args, "no_graph", False))
     gen = torch.Generator(device=dev).manual_seed(4321 + rank)
     x = torch.randn(batch, 3, 224, 224, device=dev, generator=gen)
     t = torch.randint(0, 1000, (batch,), device=dev, generator=gen)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 4)):        # steps 0 and 1 run launched, step 2 is captured, replays from then on
         loss, _ = tr.step(x, t)
     torch.cuda.synchronize()
     barrier(world)
@@ -580,6 +615,7 @@ def bench_imagenet(args, world, rank, dev, barrier, max_over_ranks):
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"erfnet_imagenet.ERFNet(1000) training step (fwd + CE + bwd + RCCL all-reduce + SGD), batch {batch}/GPU, "
-                               f"3x224x224, data parallel x{world}", "global_batch": batch * world, "final_loss": float(loss)},
+                               f"3x224x224, data parallel x{world}", "global_batch": batch * world, "final_loss": float(loss),
+                   "hip_graph": bool(tr._graphs)},
         "model_tflops": value * 12.35e9 / 1e12,
     }

@@ -102,3 +102,28 @@ def test_train_step_and_sgd_vs_golden():
         if pre_bn_bias(k):
             continue
         assert abs(ps[i] - gold_ps[i]) <= 2e-3 * max(abs(gold_ps[i]), 1.0) + 0.1 * 2e-2 * gn[i] * np.sqrt(tr.offsets[k][1]), k
+
+
+def test_sgd_step_replayed_from_a_graph_equals_the_launched_step():
+    """ArenaSGD(graph=True): steps 0 and 1 run launched, step 2 is captured and replayed, steps 3-4 are replays; dropout on (the
+    seed counter lives on the device in both modes).  Loss, gradients, parameters and momentum buffers bit for bit."""
+    from erfnet_pytorch_amd.trainer import ArenaSGD
+    x = S.synthetic_images(2, 224, 224, seed=61).to(DEV)
+    t = torch.randint(0, 1000, (2,), generator=torch.Generator().manual_seed(5)).to(DEV)
+    res = []
+    for graph in (False, True):
+        torch.manual_seed(77)                       # the dropout seed state follows torch's seed
+        m, _ = _model()
+        m.train()
+        m.compute_dtype = torch.bfloat16
+        tr = ArenaSGD(m, lr=0.05, momentum=0.9, weight_decay=1e-4, graph=graph)
+        losses = []
+        for _ in range(5):
+            loss, _ = tr.step(x, t)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert bool(tr._graphs) == graph and tr.step_count == 5
+        res.append((losses, tr.gflat.cpu().numpy().copy(), tr.flat.cpu().numpy().copy(), tr.buf.cpu().numpy().copy()))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
