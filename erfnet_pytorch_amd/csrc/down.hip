@@ -122,7 +122,33 @@ void down_kernel(const DownParams p) {
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(lbk[ks]));
     const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    // scale / shift of the pooled channels this thread writes: the same for every tile (loading them inside the tile loop put
+    // a memory round trip between the matrix phase and the stores of every tile)
+    // (in registers only where they are there: the 64 -> 128 instance holds 72 weight registers and would spill; it keeps
+    // the 2 x CIN values in LDS behind the staging area instead)
+    constexpr bool HOIST = CIN <= 16;
+    constexpr int AFF = STG + R * 16 * COUT * 2;
+    if constexpr (!HOIST) {
+        for (int i = tid; i < CIN; i += NT) {
+            ((float*)(smem + AFF))[i] = p.scale ? p.scale[CC + i] : 1.f;
+            ((float*)(smem + AFF))[CIN + i] = p.shift ? p.shift[CC + i] : 0.f;
+        }
+        ERF_LDS_BARRIER();
+    }
+    float pool_s[HOIST ? NP : 1][8], pool_t[HOIST ? NP : 1][8];
+#pragma unroll
+    for (int it = 0; it < (HOIST ? NP : 0); ++it) {
+        const int ch0 = CC + ((tid + it * NT) % CH) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pool_s[it][e] = p.scale ? p.scale[ch0 + e] : 1.f;
+            pool_t[it][e] = p.shift ? p.shift[ch0 + e] : 0.f;
+        }
+    }
+    // Tile decode + input DMA as one step: a tile's input is requested as soon as the previous tile's has been consumed
+    // (before that tile's read-back and stores), not at the top of its own iteration.
+    struct TileGeo { int n, oh0, ow0; };
+    auto request = [&](int tile) {
         uint32_t t = (uint32_t)tile;
         uint32_t nq = fast_div(t, p.fCB);
         const int cb = (int)(t - nq * p.fCB.div); t = nq;
@@ -137,8 +163,6 @@ void down_kernel(const DownParams p) {
         uhi = uhi < NROW ? uhi : NROW;
         const int wlo = ow0 == 0 ? 1 : 0;
         const int whi = W - (2 * ow0 - 1);
-
-        // ---- input tile -> LDS
 #pragma unroll
         for (int k = 0; k < KI; ++k) {
             const int u = in_uw[k] >> 8, wr = in_uw[k] & 0xFF;
@@ -146,6 +170,12 @@ void down_kernel(const DownParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + (k * NW + wave) * 1024), 16,
                                                      ok ? in_rel[k] : ERF_OOB, in_soff, 0, 0);
         }
+        return TileGeo{n, oh0, ow0};
+    };
+    TileGeo geo = {0, 0, 0};
+    if ((int)blockIdx.x < p.ntiles) geo = request(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int n = geo.n, oh0 = geo.oh0, ow0 = geo.ow0;
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
         // ---- MFMA: rows of 16 output pixels x this wave's channel tiles
@@ -199,16 +229,19 @@ void down_kernel(const DownParams p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], f[e]);
                     }
-                const int ch0 = CC + chunk * 8;
+                if constexpr (HOIST) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float s_ = p.scale ? p.scale[ch0 + e] : 1.f, t_ = p.shift ? p.shift[ch0 + e] : 0.f;
-                    best[e] = fmaxf(best[e] * s_ + t_, floor_v);
+                    for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e] * pool_s[it][e] + pool_t[it][e], floor_v);
+                } else {
+                    const float* const as_ = (const float*)(smem + AFF) + chunk * 8;      // staged once per launch, see above
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e] * as_[e] + as_[CIN + e], floor_v);
                 }
                 *(i32x4*)(smem + STG + m * OPIXB + swz<OPIXB>(m, CC / 8 + chunk) * 16) = ChunkOps<T>::pack(best);
             }
         }
         ERF_LDS_BARRIER();
+        if (tile + (int)gridDim.x < p.ntiles) geo = request(tile + gridDim.x);      // the input tile has been consumed
 
         // ---- coalesced stores of whole output pixels
         i32x4 outv[NS];
@@ -235,7 +268,7 @@ void down_kernel(const DownParams p) {
 template <int CIN, int COUT, int WM, int WN, int R, int KI>
 static int launch_down(DownParams p, hipStream_t stream) {
     constexpr int NW = WM * WN;
-    constexpr size_t lds = (size_t)KI * NW * 1024 + (size_t)R * 16 * COUT * 2;
+    constexpr size_t lds = (size_t)KI * NW * 1024 + (size_t)R * 16 * COUT * 2 + (CIN <= 16 ? 0 : 2 * CIN * sizeof(float));
     static_assert(lds <= 160 * 1024, "LDS budget");
     constexpr int OCC = 2 * lds <= 160 * 1024 ? 2 : 1;
     const int Ho = p.Hin / 2, Wo = p.Win / 2;
