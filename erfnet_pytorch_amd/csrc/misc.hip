@@ -26,6 +26,24 @@ __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T*
     float in[27];
     const long long plane = (long long)Hin * Win;
     const TIN* xb = x + (long long)n * 3 * plane;
+    if constexpr (sizeof(TIN) == 4) {
+        // fp32 image: the three taps of a row come from two aligned 8-byte loads, columns (2wo-2, 2wo-1) and (2wo, 2wo+1):
+        // a wave's lanes then cover one contiguous 512-byte run per instruction, 18 instructions instead of 27 four-byte
+        // loads two elements apart -- the kernel was bound by the address path of those, not by memory or arithmetic.
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+                const int hi = 2 * ho - 1 + th;
+                const bool rowok = hi >= 0 && hi < Hin;
+                const float* row = (const float*)xb + c * plane + (long long)(rowok ? hi : 0) * Win + 2 * wo;
+                const f32x2 lft = *(const f32x2*)(wo > 0 ? row - 2 : row);
+                const f32x2 rgt = *(const f32x2*)row;
+                in[c * 9 + th * 3 + 0] = (rowok && wo > 0) ? lft[1] : 0.f;
+                in[c * 9 + th * 3 + 1] = rowok ? rgt[0] : 0.f;
+                in[c * 9 + th * 3 + 2] = rowok ? rgt[1] : 0.f;
+            }
+    } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -37,6 +55,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T*
                 if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) v = Elem<TIN>::ld(xb + c * plane + (long long)hi * Win + wi);
                 in[c * 9 + th * 3 + tw] = v;
             }
+    }
     float out[16];
 #pragma unroll
     for (int co = 0; co < 13; ++co) {
@@ -59,8 +78,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T*
         out[c] = relu ? fmaxf(v, 0.f) : v;
     }
     T* yp = y + pix * 16;
+    if constexpr (sizeof(T) == 2) {                    // the pixel's 32 bytes as two 16-byte stores
 #pragma unroll
-    for (int c = 0; c < 16; c += 4) store4<T>(yp + c, f32x4{out[c], out[c + 1], out[c + 2], out[c + 3]});
+        for (int h = 0; h < 2; ++h) {
+            i32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(out[8 * h + 2 * e], out[8 * h + 2 * e + 1]);
+            *(i32x4*)(yp + 8 * h) = v;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c += 4) store4<T>(yp + c, f32x4{out[c], out[c + 1], out[c + 2], out[c + 3]});
+    }
 }
 
 int stem_launch(const void* x, int x_dtype, void* y, const float* w, const float* scale, const float* shift, int dtype,
