@@ -159,6 +159,31 @@ def test_output_conv_logits_and_fused_argmax(nc, dtype, tol):
     assert torch.equal(ops.argmax_c(logits).cpu(), labels.cpu())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nc", [1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 19, 21, 29, 32])
+def test_output_conv_every_class_count(nc, dtype):
+    """Decoder.output_conv for class counts on both sides of every 4-class channel tile (the labels-only kernel masks the classes
+    beyond nc of the last tile by a select, the logits kernels by folded bounds): logits against torch's ConvTranspose2d, and the
+    labels of the labels-only launch == arg-max of the logits launch, bit for bit; odd spatial sizes."""
+    from erfnet_pytorch_amd import ops
+    gen = torch.Generator().manual_seed(900 + nc)
+    w = torch.randn(16, nc, 2, 2, generator=gen) * 0.3
+    b = torch.randn(nc, generator=gen) * 0.2
+    x = torch.relu(torch.randn(2, 16, 7, 10, generator=gen))
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv_transpose2d(x, w, b, stride=2)
+    code = ops.dt(torch.empty(0, dtype=dtype))
+    packed = ops.pack_output_conv(w.to(_dev()), code)
+    logits, labels = ops.output_conv(_nhwc(x, dtype), packed, b.to(_dev()), nc, True, True, True)
+    assert rel_err(logits.cpu(), ref) <= (1e-5 if dtype == torch.float32 else 1e-5)      # same rounded operands, fp32 accumulation
+    assert torch.equal(labels.cpu(), logits.cpu().max(1)[1])
+    only = ops.output_conv(_nhwc(x, dtype), packed, b.to(_dev()), nc, False, True, True, torch.uint8)[1]
+    assert torch.equal(only.cpu().long(), labels.cpu())
+    only64 = ops.output_conv(_nhwc(x, dtype), packed, b.to(_dev()), nc, False, True, True)[1]
+    assert torch.equal(only64.cpu(), labels.cpu())
+
+
 def test_argmax_ties_first_index_wins():
     from erfnet_pytorch_amd import ops
     z = torch.zeros(1, 5, 4, 8)
