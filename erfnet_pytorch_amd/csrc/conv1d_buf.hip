@@ -492,6 +492,19 @@ static int launch_buf(BufParams p, int N, int H, int W, int axis, int* groups, h
     return erf_check_launch();
 }
 
+// Tiles of an M-pixel tiling (the count launch_buf arrives at), to compare tilings before one is launched.
+static long long buf_tiles(int N, int H, int W, int axis, int d, int M) {
+    const int A = axis == 0 ? H : W, Bn = axis == 0 ? W : N * H, nimg = axis == 0 ? N : 1;
+    const int npts = (A + d - 1) / d, tm_max = axis == 0 ? 8 : 32;
+    int Tm = 2;
+    while (Tm * 2 <= npts && Tm * 2 <= tm_max && Tm * 2 <= M / 16) Tm *= 2;
+    const int Tn = M / Tm;
+    return (long long)nimg * d * ((npts + Tm - 1) / Tm) * ((Bn + Tn - 1) / Tn);
+}
+
+// Share of the last round of a 256-workgroup launch that has work: 384 tiles keep half the CUs idle in round two.
+static double buf_fill(long long nt) { return (double)nt / (double)(((nt + 255) / 256) * 256); }
+
 // Largest number of partial statistic rows a launch can produce (size of the `stats` buffer in rows of 2C doubles).
 int conv1d_buf_max_groups() { return 512; }
 
@@ -510,7 +523,12 @@ int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* s
     int rc = ERF_EUNSUPPORTED;
     if (dtype == 1) {
         if (C == 128) {
-            rc = launch_buf<bf16raw, 128, 1, 8, 128, 5>(p, N, H, W, axis, groups, stream);
+            // small maps: 64-pixel tiles when they fill the rounds of the one-workgroup-per-CU grid markedly better
+            // (batch 6 at 64x128: 768 tiles = 3 full rounds instead of 384 = 1.5 rounds that cost 2)
+            const long long t128 = buf_tiles(N, H, W, axis, dilation, 128), t64 = buf_tiles(N, H, W, axis, dilation, 64);
+            if (t128 < 1024 && buf_fill(t64) * 0.9 > buf_fill(t128))
+                rc = launch_buf<bf16raw, 128, 1, 8, 64, 3>(p, N, H, W, axis, groups, stream);
+            if (rc == ERF_EUNSUPPORTED) rc = launch_buf<bf16raw, 128, 1, 8, 128, 5>(p, N, H, W, axis, groups, stream);
             if (rc == ERF_EUNSUPPORTED) rc = launch_buf<bf16raw, 128, 1, 8, 128, 6>(p, N, H, W, axis, groups, stream);
         } else if (C == 64) {
             rc = launch_buf<bf16raw, 64, 2, 2, 128, 5>(p, N, H, W, axis, groups, stream);
@@ -520,7 +538,10 @@ int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* s
         }
     } else {
         if (C == 128) {
-            rc = launch_buf<float, 128, 1, 8, 128, 10>(p, N, H, W, axis, groups, stream);
+            const long long t128 = buf_tiles(N, H, W, axis, dilation, 128), t64 = buf_tiles(N, H, W, axis, dilation, 64);
+            if (t128 < 1024 && buf_fill(t64) * 0.9 > buf_fill(t128))
+                rc = launch_buf<float, 128, 1, 8, 64, 6>(p, N, H, W, axis, groups, stream);
+            if (rc == ERF_EUNSUPPORTED) rc = launch_buf<float, 128, 1, 8, 128, 10>(p, N, H, W, axis, groups, stream);
         } else if (C == 64) {
             rc = launch_buf<float, 64, 1, 4, 128, 10>(p, N, H, W, axis, groups, stream);
             if (rc == ERF_EUNSUPPORTED) rc = launch_buf<float, 64, 1, 4, 128, 12>(p, N, H, W, axis, groups, stream);

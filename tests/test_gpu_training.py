@@ -552,7 +552,7 @@ def test_trainer_checkpoint_resume_is_interchangeable_with_torch_adam():
     assert trb.step_count == 2
 
 
-@pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 28),
+@pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 30),
                                                       (torch.bfloat16, 8e-2, (1, 512, 1024), 34)])
 def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, expected):
     """The BatchNorm backward whose reductions ride in the preceding data-gradient convolution (in-block bn1, and the
@@ -589,7 +589,8 @@ def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, exp
     ma, ya, na = run(True)
     mb, yb, nb = run(False)
     # 17 in-block bn1 + the 17 block-final BatchNorms that are followed by a non_bottleneck_1d (34 of the 39); on the
-    # small input the dilation-16 blocks (two lattice rows per residue class) fall back to the separate kernels
+    # small input (a 16x32 map at 128 channels) four dilation-16 launches, whose lattice has a single row or two columns
+    # per residue class, do not fit the tile buffer and fall back to the separate kernels
     assert nb == 0 and na == expected, (na, nb)
     assert torch.equal(ya, yb)
     for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
