@@ -33,7 +33,8 @@ def _back(y):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, FP32_TOL), (torch.bfloat16, BF16_TOL)])
-@pytest.mark.parametrize("c,shape", [(16, (2, 16, 12, 40)), (64, (2, 64, 20, 24)), (128, (1, 128, 40, 24))])
+@pytest.mark.parametrize("c,shape", [(16, (2, 16, 12, 40)), (64, (2, 64, 20, 24)), (128, (1, 128, 40, 24)),
+                                     (128, (4, 128, 64, 128))])     # the last: enough tiles for the 128-pixel tiling
 @pytest.mark.parametrize("axis,dil", [(0, 1), (1, 1), (0, 2), (1, 4), (0, 16), (1, 16), (0, 8)])
 def test_conv1d_factorized(dtype, tol, c, shape, axis, dil):
     from erfnet_pytorch_amd import ops

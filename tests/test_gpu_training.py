@@ -124,6 +124,7 @@ def test_block_train_forward_backward(tag, dtype):
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("c,shape,axis,dil", [(64, (2, 64, 24, 40), 0, 1), (64, (2, 64, 24, 40), 1, 1), (128, (1, 128, 40, 40), 0, 16),
                                               (128, (1, 128, 40, 40), 1, 8), (128, (2, 128, 16, 24), 1, 2), (16, (2, 16, 24, 48), 1, 1),
+                                              (128, (4, 128, 64, 128), 0, 2), (128, (4, 128, 64, 128), 1, 1),   # 128-pixel tiling
                                               (16, (2, 16, 24, 48), 0, 1)])
 def test_conv1d_dgrad_wgrad_primitives(dtype, tol, c, shape, axis, dil):
     """Gate-free check of the two backward GEMMs against torch-CPU autograd on identical (pre-rounded)
@@ -553,7 +554,12 @@ def test_trainer_checkpoint_resume_is_interchangeable_with_torch_adam():
 
 
 @pytest.mark.parametrize("dtype,tol,shape,expected", [(torch.float32, 2e-5, (2, 128, 256), 30),
-                                                      (torch.bfloat16, 8e-2, (1, 512, 1024), 34)])
+                                                      (torch.bfloat16, 8e-2, (1, 512, 1024), 34),
+                                                      # four images: the 128-channel maps take the 128-pixel tiling
+                                                      (torch.bfloat16, 8e-2, (4, 512, 1024), 34),
+                                                      # fp32: the two dilation-16 launches along H (4 lattice rows
+                                                      # x 32 columns + halo) exceed the 128-pixel tile buffer
+                                                      (torch.float32, 2e-5, (4, 512, 1024), 32)])
 def test_bn_backward_fused_into_data_gradient_convolution(dtype, tol, shape, expected):
     """The BatchNorm backward whose reductions ride in the preceding data-gradient convolution (in-block bn1, and the
     previous block's last BatchNorm across the block boundary) gives the gradients of the separate-kernel path.
