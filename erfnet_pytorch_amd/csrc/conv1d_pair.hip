@@ -769,6 +769,312 @@ void conv1d_pair_pc_kernel(const PairParams p) {
 #endif
 }
 
+
+// ---- Whole-row form for sparse lattices (128 channels, bf16) -------------------------------------------------------------
+// With a large dilation on a small map (d = 16 on 64 x 128) a residue class of the 2-D lattice has 4 x 8 points and the
+// lattice tiles above are mostly padding.  Here only the ROWS are split into residue classes (rows rho, rho + d, ...: at most
+// 4 of them, at most 128 pixels wide) and a class is resident in LDS as a whole (4 x 32 KB):
+//   * the 3x1 taps of output row t are the class rows t - 1, t, t + 1 (rows outside the image are skipped, not read);
+//   * along a row the 1x3 taps lie d = 16 pixels apart, i.e. exactly one 16-pixel matrix tile: intermediate tile j feeds
+//     the output tiles j + 1, j, j - 1 (taps 0, 1, 2), so every intermediate fragment is read once for three matrix
+//     instructions per channel tile, and the zero padding left and right of the row is a skipped instruction.
+// Roles as in conv1d_pair_pc_kernel: waves 0-3 run GEMM 1 of row t + 1 while waves 4-7 run GEMM 2 / epilogue / stores of row t.
+// LDS holds ONE intermediate row (4 x 32 + 32 KB = 160 KB), so the producers keep their accumulators until the consumers
+// have finished reading it: two barriers per row.  K-steps per accumulator in the order of the single launches (taps
+// ascending, chunks ascending; a skipped tap would have added zeros): bit-identical sums.
+struct RowsParams {
+    const T* x;
+    T* y;
+    const void* wA;
+    const void* wB;
+    const float *scaleA, *shiftA, *scaleB, *shiftB;
+    const T* res;
+    int d, relu;
+    int N, H, W;
+    int nclass;          // N * d row classes
+    FastDiv fD;
+    uint32_t bytes;      // N*H*W*256
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// GEMM 1 of one output row: taps TLO..THI, lbt[tap][kc] = fragment address of pixel tile 0 in that tap's class row.
+template <int TLO, int THI>
+__device__ __forceinline__ void rows_gemm1(const int (&lbt)[3][4], const i32x4 (&w)[2][12], f32x4 (&acc)[8][2]) {
+    constexpr int NTAP = THI - TLO + 1, GS = 4, NG = 8 * NTAP;           // one group = the four chunks of (pixel tile, tap)
+    i32x4 bb[2][GS];
+    auto issue = [&](auto gi, i32x4* dst) {
+        constexpr int g = decltype(gi)::value;
+        constexpr int pt = g / NTAP, tap = TLO + g % NTAP;
+        static_for<0, GS>([&](auto e) { dst[decltype(e)::value] = lds_read_b128<pt * 4096>(lbt[tap][decltype(e)::value]); });
+    };
+    issue(std::integral_constant<int, 0>{}, bb[0]);
+    static_for<0, NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        constexpr int pt = g / NTAP, tap = TLO + g % NTAP;
+        i32x4* cb = bb[g & 1];
+        if constexpr (g + 1 < NG) {
+            issue(std::integral_constant<int, g + 1>{}, bb[(g + 1) & 1]);
+            wait_lgkm<GS>();
+        } else {
+            wait_lgkm<0>();
+        }
+        static_for<0, GS>([&](auto e) { tie_reg(cb[decltype(e)::value]); });
+        static_for<0, GS>([&](auto e) {
+            constexpr int kc = decltype(e)::value, ks = tap * 4 + kc;
+            const i32x4 b = cb[kc];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                acc[pt][c] = mma_step<T>(w[c][ks], b, (tap == TLO && kc == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pt][c]);
+        });
+    });
+}
+
+// GEMM 2 of one output row from the intermediate row at lb[kc] (pixel tile 0): group j reads intermediate tile j once and
+// feeds output tiles j + 1 (tap 0), j (tap 1), j - 1 (tap 2).  epi(pt) runs one group after tile pt received its last K-step.
+template <typename EPI>
+__device__ __forceinline__ void rows_gemm2(const int (&lb)[4], const i32x4 (&w)[2][12], f32x4 (&acc)[8][2], EPI&& epi) {
+    constexpr int GS = 4, NG = 8;
+    i32x4 bb[2][GS];
+    auto issue = [&](auto gi, i32x4* dst) {
+        constexpr int j = decltype(gi)::value;
+        static_for<0, GS>([&](auto e) { dst[decltype(e)::value] = lds_read_b128<j * 4096>(lb[decltype(e)::value]); });
+    };
+    issue(std::integral_constant<int, 0>{}, bb[0]);
+    static_for<0, NG>([&](auto gi) {
+        constexpr int j = decltype(gi)::value;
+        i32x4* cb = bb[j & 1];
+        if constexpr (j + 1 < NG) {
+            issue(std::integral_constant<int, j + 1>{}, bb[(j + 1) & 1]);
+            wait_lgkm<GS>();
+        } else {
+            wait_lgkm<0>();
+        }
+        static_for<0, GS>([&](auto e) { tie_reg(cb[decltype(e)::value]); });
+        static_for<0, GS>([&](auto e) {
+            constexpr int kc = decltype(e)::value;
+            const i32x4 b = cb[kc];
+            static_for<0, 3>([&](auto ti) {
+                constexpr int tap = decltype(ti)::value, pt = j + 1 - tap;
+                if constexpr (pt >= 0 && pt < 8) {
+                    constexpr int ks = tap * 4 + kc;
+                    constexpr bool first = kc == 0 && (pt == 0 ? tap == 1 : tap == 0);       // tile 0 has no tap 0: left of the row
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[pt][c] = mma_step<T>(w[c][ks], b, first ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pt][c]);
+                }
+            });
+        });
+        if constexpr (j >= 2) epi(std::integral_constant<int, j - 2>{});      // tile j - 2 was completed by group j - 1
+    });
+    epi(std::integral_constant<int, 6>{});
+    epi(std::integral_constant<int, 7>{});
+}
+#endif
+
+template <bool POST>
+__global__ __launch_bounds__(512, 1)
+void conv1d_pair_rows_kernel(const RowsParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PIXB = 256, NP = 4, CTW = 2, KS = 12;
+    constexpr int ROWB = 128 * PIXB;                   // one class row in LDS
+    constexpr int MID = 4 * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave / NP, wn = wave % NP;
+    const int q = lane >> 4, r16 = lane & 15;
+
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, p.bytes);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y, p.bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.res ? p.res : p.x, p.bytes);
+
+    i32x4 w[CTW][KS];
+    f32x4 sc[CTW], sh[CTW];
+    {
+        const i32x4* pw = (const i32x4*)(role ? p.wB : p.wA);
+        const float* ps = role ? p.scaleB : p.scaleA;
+        const float* pt = role ? p.shiftB : p.shiftA;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[c][ks] = pw[((wn * CTW + c) * KS + ks) * 64 + lane];
+            const int co = (wn * CTW + c) * 16 + q * 4;
+            sc[c] = ps ? *(const f32x4*)(ps + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+            sh[c] = pt ? *(const f32x4*)(pt + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) tie_reg(w[c][ks]);
+        asm volatile("" : "+v"(sc[c]), "+v"(sh[c]));
+    }
+    const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
+    const uint32_t rowstep = (uint32_t)(p.d * p.W) * PIXB;               // one class row down
+
+    // The class loop is written once per role: with the role branch inside it the compiler keeps both roles' loop
+    // invariants live in registers at once, which does not fit.
+    if (role == 0) {
+        // -------------------------------------------------------------------- producers
+        for (int cls = blockIdx.x; cls < p.nclass; cls += gridDim.x) {
+            const uint32_t n = fast_div((uint32_t)cls, p.fD);
+            const int rho = cls - (int)n * p.d;
+            const int nh = rho < p.H ? (int)fast_div((uint32_t)(p.H - rho + p.d - 1), p.fD) : 0;   // rows of this class (host: at most 4)
+            const uint32_t base = (uint32_t)(((int)n * p.H + rho) * p.W) * PIXB;                 // row 0 of the class
+            // DMA of the whole class, row by row: instruction k moves pixels (k & 7) * 16 .. + 15 of row k >> 3
+            uint32_t in_rel[8];
+            int wc = p.W;                              // opaque per class: keeps these eight out of the registers live across the rows
+            asm volatile("" : "+s"(wc));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = k * 16 + wn * 4 + q;                       // lane = (pixel q of this wave's four, 16-byte slot r16)
+                in_rel[k] = j < wc ? (uint32_t)j * PIXB + swz<PIXB>(j, r16) * 16 : ERF_OOB;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int r = k >> 3;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + (k * NP + wn) * 1024), 16,
+                                                         r < nh ? in_rel[k & 7] : ERF_OOB, base + r * rowstep, 0, 0);
+            }
+            int lb1[4], mid_w[CTW];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) lb1[kc] = r16 * PIXB + swz<PIXB>(r16, kc * 4 + q) * 16;
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) {
+                const int chunk = (wn * CTW + c) * 2 + (q >> 1);
+                mid_w[c] = MID + r16 * PIXB + swz<PIXB>(r16, chunk) * 16 + (q & 1) * 8;
+            }
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // this wave's share of rows 0 and 1
+            ERF_LDS_BARRIER();
+            for (int t = 0; t <= nh; ++t) {
+                f32x4 acc[8][CTW];
+                if (t < nh) {
+                    int lbt[3][4];
+#pragma unroll
+                    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                        for (int kc = 0; kc < 4; ++kc) lbt[tap][kc] = lb1[kc] + (t - 1 + tap) * ROWB;
+                    if (t == 0) rows_gemm1<1, 2>(lbt, w, acc);           // no row above the image
+                    else if (t == 3) rows_gemm1<0, 1>(lbt, w, acc);      // LDS holds four rows; a fifth does not exist
+                    else rows_gemm1<0, 2>(lbt, w, acc);                  // a row below the image was filled with zeros by the DMA
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the rest of the class has landed (long ago)
+                }
+                ERF_LDS_BARRIER();                                       // the consumers have read the intermediate row
+                if (t < nh) {
+                    int wl = p.W;
+                    asm volatile("" : "+s"(wl));
+#pragma unroll
+                    for (int pt = 0; pt < 8; ++pt) {
+                        const bool inside = r16 < wl - pt * 16;          // pixels right of the image are the 1x3 zero padding
+#pragma unroll
+                        for (int c = 0; c < CTW; ++c) {
+                            f32x4 v = acc[pt][c];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(v[e] * sc[c][e] + sh[c][e], 0.f) : 0.f;
+                            *(i32x2*)(smem + mid_w[c] + pt * 4096) = pack_bf16x4(v);
+                        }
+                    }
+                }
+                ERF_LDS_BARRIER();                                       // intermediate row t complete
+            }
+        }
+    } else {
+        // -------------------------------------------------------------------- consumers
+        for (int cls = blockIdx.x; cls < p.nclass; cls += gridDim.x) {
+            const uint32_t n = fast_div((uint32_t)cls, p.fD);
+            const int rho = cls - (int)n * p.d;
+            const int nh = rho < p.H ? (int)fast_div((uint32_t)(p.H - rho + p.d - 1), p.fD) : 0;
+            const uint32_t base = (uint32_t)(((int)n * p.H + rho) * p.W) * PIXB;
+            int lb2[4];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) lb2[kc] = MID + r16 * PIXB + swz<PIXB>(r16, kc * 4 + q) * 16;
+            uint32_t orel[CTW];
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) orel[c] = (uint32_t)r16 * PIXB + ((wn * CTW + c) * 16 + q * 4) * 2;
+            ERF_LDS_BARRIER();
+            for (int t = 0; t <= nh; ++t) {
+                if (t >= 1) {
+                    const uint32_t rowoff = base + (uint32_t)(t - 1) * rowstep;
+                    int wl = p.W;                      // opaque per row: 16 loop-invariant masked offsets would not fit the registers
+                    asm volatile("" : "+s"(wl));
+                    i32x2 rv[8][CTW];
+                    if constexpr (POST) {
+#pragma unroll
+                        for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+                            for (int c = 0; c < CTW; ++c)
+                                rv[pt][c] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                    rs_r, r16 < wl - pt * 16 ? orel[c] : ERF_OOB, rowoff + pt * 4096, 0));
+                    }
+                    f32x4 acc[8][CTW];
+                    auto ep2 = [&](auto pti) {
+                        constexpr int pt = decltype(pti)::value;
+                        if constexpr (POST && pt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the residual pieces
+                        const bool inside = r16 < wl - pt * 16;
+#pragma unroll
+                        for (int c = 0; c < CTW; ++c) {
+                            f32x4 v = acc[pt][c];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = v[e] * sc[c][e] + sh[c][e];
+                                if constexpr (!POST) v[e] = fmaxf(v[e], floor_v);
+                            }
+                            i32x2 o = pack_bf16x4(v);
+                            if constexpr (POST) {      // rounding points of the staged epilogue: bf16, + residual, bf16
+                                f32x4 f, r;
+                                f[0] = __uint_as_float(((uint32_t)o[0]) << 16); f[1] = __uint_as_float(((uint32_t)o[0]) & 0xFFFF0000u);
+                                f[2] = __uint_as_float(((uint32_t)o[1]) << 16); f[3] = __uint_as_float(((uint32_t)o[1]) & 0xFFFF0000u);
+                                const i32x2 rr = rv[pt][c];
+                                r[0] = __uint_as_float(((uint32_t)rr[0]) << 16); r[1] = __uint_as_float(((uint32_t)rr[0]) & 0xFFFF0000u);
+                                r[2] = __uint_as_float(((uint32_t)rr[1]) << 16); r[3] = __uint_as_float(((uint32_t)rr[1]) & 0xFFFF0000u);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) f[e] = fmaxf(f[e] + r[e], floor_v);
+                                o = pack_bf16x4(f);
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_y, inside ? orel[c] : ERF_OOB,
+                                                                  rowoff + pt * 4096, 0);
+                        }
+                        // the data registers of a buffer store with an SGPR offset must not be rewritten right after its issue
+                        asm volatile("s_nop 4" ::: "memory");
+                    };
+                    rows_gemm2(lb2, w, acc, ep2);
+                }
+                ERF_LDS_BARRIER();                                       // the producers' two barriers of this row
+                ERF_LDS_BARRIER();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup
+#endif
+}
+
+// Whole-row form: 128 channels, dilation 16 (a 1x3 tap = one 16-pixel tile), rows at most 128 pixels wide, at most 4 rows
+// per residue class.
+static bool pair_rows_fits(int H, int W, int d) { return d == 16 && W >= 1 && W <= 128 && (H + d - 1) / d <= 4; }
+
+static int launch_pair_rows(const PairParams& q, hipStream_t stream) {
+    RowsParams p{};
+    p.x = q.x; p.y = q.y; p.wA = q.wA; p.wB = q.wB; p.scaleA = q.scaleA; p.shiftA = q.shiftA; p.scaleB = q.scaleB; p.shiftB = q.shiftB;
+    p.res = q.res; p.d = q.d; p.relu = q.relu; p.N = q.N; p.H = q.H; p.W = q.W;
+    if (!pair_rows_fits(p.H, p.W, p.d)) return ERF_EUNSUPPORTED;
+    const long long bytes = (long long)p.N * p.H * p.W * 256, ncls = (long long)p.N * p.d;
+    if (bytes >= 0x7FFFFFFFLL || ncls > 0x1FFFFFFF) return ERF_EUNSUPPORTED;      // 32-bit offsets, bit 31 marks masked lanes
+    p.bytes = (uint32_t)bytes; p.nclass = (int)ncls; p.fD = make_fastdiv(p.d);
+    constexpr int lds = 5 * 128 * 256;
+    const int grid = 256 < p.nclass ? 256 : p.nclass;
+    if (p.res) {
+        auto kern = conv1d_pair_rows_kernel<true>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return ERF_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    } else {
+        auto kern = conv1d_pair_rows_kernel<false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return ERF_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    }
+    return erf_check_launch();
+}
+
 template <int C, int R, int TC>
 static int launch_pair_pc(PairParams p, hipStream_t stream) {
     constexpr int PIXB = C * 2;
@@ -852,7 +1158,7 @@ int conv1d_pair_launch(const void* x, void* y, const void* packedA, const void* 
     // Sparse lattices (few points per residue class) waste most of a tile: leave those to two single launches.
     if (C == 128) {
         const double u16 = pair_utilization(H, W, dilation, 8, 16), u32 = pair_utilization(H, W, dilation, 4, 32);
-        if (u16 < 0.6 && u32 < 0.6) return ERF_EUNSUPPORTED;
+        if (u16 < 0.6 && u32 < 0.6) return pair_rows_fits(H, W, dilation) ? launch_pair_rows(p, stream) : ERF_EUNSUPPORTED;
         if (u32 > u16 * 1.1) return launch_pair<128, 1, 8, 128, 32, 6>(p, stream);
         static const int pc_off = erf_debug_env("ERF_PAIR_PC_OFF", 0);
         if (!pc_off) return launch_pair_pc<128, 8, 16>(p, stream);

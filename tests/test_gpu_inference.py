@@ -60,6 +60,10 @@ def test_conv1d_factorized(dtype, tol, c, shape, axis, dil):
 @pytest.mark.parametrize("c,shape,dil", [
     (128, (2, 128, 64, 128), 1), (128, (1, 128, 64, 128), 2), (128, (1, 128, 64, 128), 4), (128, (2, 128, 64, 128), 8),
     (128, (1, 128, 37, 53), 2), (128, (1, 128, 23, 70), 1), (128, (1, 128, 45, 62), 4),
+    # dilation 16 on maps of at most 64 x 128: the whole-row kernel (4 or 3 rows per residue class, ragged widths; at least
+    # 49 rows and columns, below that the single launches fall back to the generic kernel with its own summation order)
+    (128, (2, 128, 64, 128), 16), (128, (1, 128, 50, 100), 16), (128, (3, 128, 49, 53), 16),
+    (128, (20, 128, 64, 128), 16),       # more classes than workgroups
     (64, (1, 64, 128, 256), 1), (64, (2, 64, 19, 41), 1), (64, (1, 64, 33, 30), 2),
     (16, (1, 16, 256, 512), 1), (16, (2, 16, 50, 70), 1), (16, (1, 16, 61, 30), 1),
 ])
@@ -94,14 +98,45 @@ def test_conv1d_pair_equals_two_launches_and_reference(c, shape, dil, with_res):
     assert bool((diff <= ulp).all()), f"max diff {diff.max().item()} at {(diff / ulp).max().item()} ulp"
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 20, 37), (1, 128, 9, 16), (2, 128, 16, 128), (1, 128, 17, 5), (3, 128, 40, 37),
+                                   (1, 128, 33, 16), (2, 128, 64, 90)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv1d_pair_whole_rows_small_maps(shape, with_res):
+    """Dilation 16 on small maps: one to four rows per residue class, widths that leave matrix tiles partly or wholly
+    empty.  Below 49 rows or columns the single launches fall back to the generic kernel (another summation order), so
+    this compares with the fp32 torch reference only."""
+    from erfnet_pytorch_amd import ops
+    c, dil, seed = 128, 16, 77 + shape[2]
+    x = activations(shape, seed) - 0.3
+    wa = S.fill_tensor("p.a.weight", (c, c, 3, 1), salt=seed)
+    wb = S.fill_tensor("p.b.weight", (c, c, 1, 3), salt=seed)
+    ba = S.fill_tensor("p.a.bias", (c,), salt=seed)
+    bb = S.fill_tensor("p.b.bias", (c,), salt=seed)
+    sb = S.fill_tensor("p.bn.weight", (c,), salt=seed)
+    res = activations(shape, seed + 1) if with_res else None
+    mid = F.relu(F.conv2d(x, wa, ba, padding=(dil, 0), dilation=(dil, 1)))
+    ref = F.conv2d(mid, wb, None, padding=(0, dil), dilation=(1, dil)) * sb[None, :, None, None] + bb[None, :, None, None]
+    ref = F.relu(ref + res) if with_res else F.relu(ref)
+    code = ops.dt(torch.empty(0, dtype=torch.bfloat16))
+    pa, pb = ops.pack_conv1d(wa.to(_dev()), code), ops.pack_conv1d(wb.to(_dev()), code)
+    rd = _nhwc(res, torch.bfloat16) if with_res else None
+    y = ops.conv1d_pair(_nhwc(x, torch.bfloat16), pa, ba.to(_dev()), pb, sb.to(_dev()), bb.to(_dev()), rd, dil, True)
+    assert y is not None, "shape should be taken by the whole-row kernel"
+    torch.cuda.synchronize()
+    assert rel_err(_back(y), ref) <= BF16_TOL
+
+
 def test_conv1d_pair_declines_sparse_lattices_and_fp32():
     from erfnet_pytorch_amd import ops
     code = ops.dt(torch.empty(0, dtype=torch.bfloat16))
     w = S.fill_tensor("p.a.weight", (128, 128, 3, 1), salt=1).to(_dev())
     pk = ops.pack_conv1d(w, code)
     b = torch.zeros(128, device=_dev())
+    x = torch.zeros(1, 64, 200, 128, device=_dev(), dtype=torch.bfloat16)
+    assert ops.conv1d_pair(x, pk, b, pk, None, b, None, 16, True) is None            # 4 x 13 points per residue class, rows wider than 128
+    x = torch.zeros(1, 30, 60, 128, device=_dev(), dtype=torch.bfloat16)
+    assert ops.conv1d_pair(x, pk, b, pk, None, b, None, 8, True) is None             # 4 x 8 points, but not dilation 16
     x = torch.zeros(1, 64, 128, 128, device=_dev(), dtype=torch.bfloat16)
-    assert ops.conv1d_pair(x, pk, b, pk, None, b, None, 16, True) is None            # 4 x 8 points per residue class
     pk32 = ops.pack_conv1d(w, ops.dt(torch.empty(0)))
     assert ops.conv1d_pair(x.float(), pk32, b, pk32, None, b, None, 1, True) is None
 
