@@ -800,17 +800,19 @@ struct RowsParams {
 // GEMM 1 of one output row: taps TLO..THI, lbt[tap][kc] = fragment address of pixel tile 0 in that tap's class row.
 template <int TLO, int THI>
 __device__ __forceinline__ void rows_gemm1(const int (&lbt)[3][4], const i32x4 (&w)[2][12], f32x4 (&acc)[8][2]) {
-    constexpr int NTAP = THI - TLO + 1, GS = 4, NG = 8 * NTAP;           // one group = the four chunks of (pixel tile, tap)
+    constexpr int NTAP = THI - TLO + 1, NR = 8 * NTAP * 4;                // reads in the order (pixel tile, tap, chunk)
+    constexpr int GS = NR % 6 == 0 ? 6 : 4, NG = NR / GS;
     i32x4 bb[2][GS];
     auto issue = [&](auto gi, i32x4* dst) {
-        constexpr int g = decltype(gi)::value;
-        constexpr int pt = g / NTAP, tap = TLO + g % NTAP;
-        static_for<0, GS>([&](auto e) { dst[decltype(e)::value] = lds_read_b128<pt * 4096>(lbt[tap][decltype(e)::value]); });
+        static_for<0, GS>([&](auto e) {
+            constexpr int r = decltype(gi)::value * GS + decltype(e)::value;
+            constexpr int pt = r / (NTAP * 4), tap = TLO + (r / 4) % NTAP, kc = r % 4;
+            dst[decltype(e)::value] = lds_read_b128<pt * 4096>(lbt[tap][kc]);
+        });
     };
     issue(std::integral_constant<int, 0>{}, bb[0]);
     static_for<0, NG>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
-        constexpr int pt = g / NTAP, tap = TLO + g % NTAP;
         i32x4* cb = bb[g & 1];
         if constexpr (g + 1 < NG) {
             issue(std::integral_constant<int, g + 1>{}, bb[(g + 1) & 1]);
@@ -820,8 +822,9 @@ __device__ __forceinline__ void rows_gemm1(const int (&lbt)[3][4], const i32x4 (
         }
         static_for<0, GS>([&](auto e) { tie_reg(cb[decltype(e)::value]); });
         static_for<0, GS>([&](auto e) {
-            constexpr int kc = decltype(e)::value, ks = tap * 4 + kc;
-            const i32x4 b = cb[kc];
+            constexpr int r = g * GS + decltype(e)::value;
+            constexpr int pt = r / (NTAP * 4), tap = TLO + (r / 4) % NTAP, kc = r % 4, ks = tap * 4 + kc;
+            const i32x4 b = cb[decltype(e)::value];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
                 acc[pt][c] = mma_step<T>(w[c][ks], b, (tap == TLO && kc == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pt][c]);
@@ -958,7 +961,10 @@ void conv1d_pair_rows_kernel(const RowsParams p) {
                     if (t == 0) rows_gemm1<1, 2>(lbt, w, acc);           // no row above the image
                     else if (t == 3) rows_gemm1<0, 1>(lbt, w, acc);      // LDS holds four rows; a fifth does not exist
                     else rows_gemm1<0, 2>(lbt, w, acc);                  // a row below the image was filled with zeros by the DMA
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the rest of the class has landed (long ago)
+                    // row t + 2 is needed next: every workgroup streams its class in at launch start, so the rows land
+                    // one after the other and the last one is not worth waiting for after the first row's matrix work
+                    if (t == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 ERF_LDS_BARRIER();                                       // the consumers have read the intermediate row
                 if (t < nh) {

@@ -1,5 +1,5 @@
 """Times the fused conv3x1 -> conv1x3 launch at 128 channels, dilation 16 (whole-row kernel) on a 16 x 64 x 128 map,
-with and without the residual, against the two single launches it replaces.  Usage: python scripts/pair_rows_time.py"""
+with and without the residual, against the two single launches it replaces.  Usage: python scripts/pair_rows_time.py [batch ...]"""
 import os
 import sys
 
@@ -22,12 +22,12 @@ def timed(fn, n=200):
     return a.elapsed_time(b) / n * 1e3
 
 
-def main():
+def run(nb):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     c, d = 128, 16
-    x = torch.randn(16, 64, 128, c, device=dev).to(torch.bfloat16)
-    r = torch.randn(16, 64, 128, c, device=dev).to(torch.bfloat16)
+    x = torch.randn(nb, 64, 128, c, device=dev).to(torch.bfloat16)
+    r = torch.randn(nb, 64, 128, c, device=dev).to(torch.bfloat16)
     code = ops.dt(x)
     pa = ops.pack_conv1d(torch.randn(c, c, 3, 1, device=dev) * 0.05, code)
     pb = ops.pack_conv1d(torch.randn(c, c, 1, 3, device=dev) * 0.05, code)
@@ -39,8 +39,9 @@ def main():
         def singles():
             m = ops.conv1d(x, pa, None, ba, None, 0, d, True)
             return ops.conv1d(m, pb, sb, bb, res, 1, d, True)
-        print(f"{tag}: fused {t:.1f} us, two single launches {timed(singles):.1f} us", flush=True)
+        print(f"batch {nb} {tag}: fused {t:.1f} us, two single launches {timed(singles):.1f} us", flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    for nb in ([int(a) for a in sys.argv[1:]] or [16]):
+        run(nb)
