@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--infer-ways", type=int, default=2,
+                    help="inference: cut the batch into this many runs of images, each a chain of launches on its own HIP stream "
+                         "(ERFNet.predict_labels(ways=...); bit-identical labels; 1 = one chain)")
     ap.add_argument("--train-graph", action="store_true", help="N > 1: capture the training step (RCCL all-reduces included) into a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -256,7 +259,7 @@ def run_infer(args, world, rank, dev, dtype=None, steps=None, warmup=None, roofl
 
     def step():
         with torch.no_grad():
-            labels = model.predict_labels(x, torch.uint8)
+            labels = model.predict_labels(x, torch.uint8, ways=args.infer_ways)
             ev.addBatch(labels.unsqueeze(1), target)
 
     step()                                    # packs weights, allocates the histogram
@@ -287,7 +290,7 @@ def run_infer(args, world, rank, dev, dtype=None, steps=None, warmup=None, roofl
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"ERFNet({args.classes}) inference + fused argmax + iouEval histogram, batch {batch}/GPU, "
                                f"3x{args.height}x{args.width}, {'independent shards per rank' if world > 1 else 'single GPU'}",
-                   "hip_graph": graph is not None, "synthetic_miou": miou},
+                   "hip_graph": graph is not None, "streams": max(1, min(args.infer_ways, batch)), "synthetic_miou": miou},
     }
     if rank == 0:
         flops = FWD_FLOP_PER_IMG * (args.height * args.width) / (512 * 1024)

@@ -231,11 +231,12 @@ class Decoder(nn.Module):
             self.__dict__["_erf_head"] = cache
         return cache[1], cache[2]
 
-    def forward_nhwc(self, x, logits_f32=True, want_logits=True, want_labels=False, label_dtype=torch.int64):
+    def forward_nhwc(self, x, logits_f32=True, want_logits=True, want_labels=False, label_dtype=torch.int64, labels_out=None):
         for layer in self.layers:
             x = layer.forward_nhwc(x)
         w, b = self._head(ops.dt(x))
-        return ops.output_conv(x, w, b, self.output_conv.out_channels, want_logits, logits_f32, want_labels, label_dtype)
+        return ops.output_conv(x, w, b, self.output_conv.out_channels, want_logits, logits_f32, want_labels, label_dtype,
+                               labels_out=labels_out)
 
     def forward(self, input):
         ops.require_gpu(input, "Decoder")
@@ -273,14 +274,52 @@ class ERFNet(nn.Module):
         return logits
 
     @torch.no_grad()
-    def predict_labels(self, input, label_dtype=torch.int64, with_logits=False):
+    def predict_labels(self, input, label_dtype=torch.int64, with_logits=False, ways=1):
         """outputs.max(1)[1] without materialising the logits: the arg-max is taken from the fp32
-        accumulators inside the output_conv kernel.  Returns labels [N,H,W] (and logits if asked)."""
+        accumulators inside the output_conv kernel.  Returns labels [N,H,W] (and logits if asked).
+
+        ways > 1 (labels only): the batch is cut into `ways` runs of images, each a chain of launches on its own HIP stream
+        (forked from and joined to the caller's stream, so the call composes with graph capture).  Images are independent,
+        so the labels are bit-identical; what changes is that one chain's launch prologues (every workgroup first loads its
+        weights) and tails (the last, partly filled round of workgroups) run under the other chain's tiles."""
         ops.require_gpu(input, "ERFNet")
+        if ways > 1 and not with_logits and input.shape[0] >= ways:
+            return self._predict_labels_split(input, label_dtype, int(ways))
         x = self.encoder.forward_features_nhwc(input, self._code(input))
         logits, labels = self.decoder.forward_nhwc(x, logits_f32=True, want_logits=with_logits, want_labels=True,
                                                    label_dtype=label_dtype)
         return (labels, logits) if with_logits else labels
+
+    def _predict_labels_split(self, input, label_dtype, ways):
+        code = self._code(input)
+        # packed weights / folded affines are (re)built on the caller's stream BEFORE the chains fork: built inside one
+        # chain they would be read by the others without any ordering
+        for m in self.modules():
+            if isinstance(m, _Block):
+                m._cached(code)
+        self.decoder._head(code)
+        n, _, h, w = input.shape
+        labels = torch.empty((n, h, w), dtype=label_dtype, device=input.device)
+        cur = torch.cuda.current_stream(input.device)
+        side = self.__dict__.get("_erf_side_streams")
+        if side is None or len(side) < ways - 1 or side[0].device != input.device:
+            side = [torch.cuda.Stream(input.device) for _ in range(ways - 1)]
+            self.__dict__["_erf_side_streams"] = side
+        per = (n + ways - 1) // ways
+        runs = [(a, min(a + per, n)) for a in range(0, n, per)]
+
+        def chain(a, b):
+            x = self.encoder.forward_features_nhwc(input[a:b], code)
+            self.decoder.forward_nhwc(x, want_logits=False, want_labels=True, label_dtype=label_dtype, labels_out=labels[a:b])
+
+        for (a, b), s in zip(runs[1:], side):
+            s.wait_stream(cur)                 # the input, the label buffer and the packed weights are ready
+            with torch.cuda.stream(s):
+                chain(a, b)
+        chain(*runs[0])
+        for _, s in zip(runs[1:], side):
+            cur.wait_stream(s)
+        return labels
 
 
 Net = ERFNet

@@ -424,3 +424,34 @@ def test_iou_eval_plane_inputs_vs_golden():
         assert torch.equal(ev.tp, 2 * ev2.tp) and torch.equal(ev.fp, 2 * ev2.fp) and torch.equal(ev.fn, 2 * ev2.fn)
         with pytest.raises(ValueError):
             iouEval(nc).addBatch(x[:, :-1].to(_dev()), y.to(_dev()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, None])
+def test_predict_labels_split_over_streams_is_bit_identical(dtype):
+    """ERFNet.predict_labels(ways=k): the batch cut into k runs of images on k HIP streams gives the labels of the single
+    chain bit for bit (images are independent), launched and replayed from a HIP graph, for even and uneven cuts, and after
+    the weights changed (the packed copies are rebuilt before the chains fork)."""
+    from erfnet_pytorch_amd import erfnet as E
+    model = E.ERFNet(20)
+    model.load_state_dict(O.synthetic_state(O.erfnet_template(20)))
+    model = model.to(_dev()).eval()
+    model.compute_dtype = dtype
+    x = S.synthetic_images(5, 64, 128, seed=11).to(_dev())
+    one = model.predict_labels(x, torch.uint8)
+    for ways in (2, 3, 5, 8):
+        assert torch.equal(model.predict_labels(x, torch.uint8, ways=ways), one), ways
+    assert torch.equal(model.predict_labels(x, torch.int64, ways=2), one.long())
+    static_x = x.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        out = model.predict_labels(static_x, torch.uint8, ways=2)
+    static_x.copy_(S.synthetic_images(5, 64, 128, seed=12).to(_dev()))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, model.predict_labels(static_x, torch.uint8))
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+    again = model.predict_labels(x, torch.uint8, ways=2)          # first call after the change is a split one
+    assert torch.equal(again, model.predict_labels(x, torch.uint8))
+
