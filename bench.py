@@ -5,10 +5,13 @@
 
 N = 1, headline (`value`): BASELINE.json configs[1] -- ERFNet(20) inference, batch 16, bf16 activations with fp32
   accumulation, 3x512x1024 synthetic images resident in HBM, fused arg-max and the iouEval confusion histogram; one
-  step = one batch through the whole pipeline, replayed from a HIP graph.  The same line carries
+  step = one batch through the whole pipeline, replayed from a HIP graph; the batch runs as two chains of launches on two
+  HIP streams (ERFNet.predict_labels(ways=2): images 0-7 and 8-15, bit-identical labels; `--infer-ways 1` = one chain).
+  The same line carries
+    "inference_one_chain" the same leg with one chain of launches (short leg),
     "training"       BASELINE.json configs[2]: the bf16 training step, batch 6 (its own steps / warm-up),
     "fp32"           {"inference", "training"}: the same two legs with fp32 storage (short legs),
-    "roofline"       the dominant kernel alone, timed here with events on the launch stream,
+    "roofline"       the dominant kernel alone (full-batch launches, one chain), timed here with events on the launch stream,
     "roofline_block" the same measurement priced per non_bottleneck_1d block against the block's algorithmic bytes
                      (x in, y out), which shows what the two-launch block spends above the one-pass model,
     "cpu_baseline"   the oracle's fp32 forward, b=1, on this box's host cores (eval_forwardTime protocol).
@@ -383,6 +386,11 @@ def main():
         # auto, one GPU: inference is the headline; training, and both legs in fp32, ride in the same line
         res = run_infer(args, world, rank, dev)
         free_gpu()
+        if args.infer_ways > 1:
+            one = argparse.Namespace(**vars(args))
+            one.infer_ways = 1
+            res["inference_one_chain"] = leg(run_infer(one, world, rank, dev, steps=15, warmup=3, roofline=False))
+            free_gpu()
         if not args.no_train:
             res["training"] = leg(run_train(args, world, rank, dev, steps=args.train_steps, warmup=args.train_warmup, batch=args.train_batch))
             free_gpu()
