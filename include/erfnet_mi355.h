@@ -64,7 +64,8 @@ int erf_conv1d_factorized(const void* x, void* y, const void* packed, const floa
  *     y = act( scale_b * conv1x3_d( relu( scale_a * conv3x1_d(x) + shift_a ) ) + shift_b (+ residual) )
  * packed_a / packed_b: mode-0 packed weights of the 3x1 and the 1x3 convolution.  bf16 only.
  * Returns ERF_EUNSUPPORTED (-2) without launching for shapes it does not take (fp32, or a dilation
- * that leaves too few pixels per residue class): issue two erf_conv1d_factorized calls then. */
+ * that leaves too few pixels per residue class -- except C = 128, dilation 16 on maps of at most 64 x 128, which a kernel
+ * working on whole image rows takes): issue two erf_conv1d_factorized calls then. */
 int erf_conv1d_pair(const void* x, void* y, const void* packed_a, const void* packed_b, const float* scale_a,
                     const float* shift_a, const float* scale_b, const float* shift_b, const void* residual, int dtype,
                     int N, int H, int W, int C, int dilation, int relu, void* stream);
