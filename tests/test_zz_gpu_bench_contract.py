@@ -1,5 +1,5 @@
 """bench.py's one-line JSON contract, on small shapes: the keys the driver reads, the objects this repository adds
-(roofline, roofline_block, cpu_baseline, training, fp32) at N = 1, and at N = 2 (rehearsal: both ranks on the one GPU, gloo)
+(roofline, roofline_block, cpu_baseline, inference_one_chain, training, fp32) at N = 1, and at N = 2 (rehearsal: both ranks on the one GPU, gloo)
 the training step as the headline with the inference leg, the process group's world size and the per-bucket all-reduce
 times beside it."""
 import json
@@ -31,6 +31,9 @@ def test_single_gpu_line_has_every_leg():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "bf16" and d["unit"] == "img/s"
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["world_size"] == 1
     assert "inference" in d["config"]["workload"] and d["config"]["hip_graph"] is True
+    assert d["config"]["streams"] == 2                      # the batch as two chains of launches; the one-chain leg beside it
+    one = d["inference_one_chain"]
+    assert one["config"]["streams"] == 1 and one["value"] > 0 and one["dtype"] == "bf16"
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
