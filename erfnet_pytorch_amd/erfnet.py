@@ -29,6 +29,9 @@ FUSE_PAIRS = True     # inference: one launch per conv3x1 -> conv1x3 pair where 
 FUSE_BLOCKS = (16,)
 
 
+_SIDE_STREAMS = {}       # device index -> side streams of ERFNet.predict_labels(ways=k)
+
+
 def _versions(mod: nn.Module):
     return tuple((t.data_ptr(), t._version) for t in list(mod.parameters(recurse=False)) + list(mod.buffers(recurse=False)))
 
@@ -301,10 +304,9 @@ class ERFNet(nn.Module):
         n, _, h, w = input.shape
         labels = torch.empty((n, h, w), dtype=label_dtype, device=input.device)
         cur = torch.cuda.current_stream(input.device)
-        side = self.__dict__.get("_erf_side_streams")
-        if side is None or len(side) < ways - 1 or side[0].device != input.device:
-            side = [torch.cuda.Stream(input.device) for _ in range(ways - 1)]
-            self.__dict__["_erf_side_streams"] = side
+        side = _SIDE_STREAMS.setdefault(input.device.index, [])      # per device, not on the module: a module must stay copyable
+        while len(side) < ways - 1:
+            side.append(torch.cuda.Stream(input.device))
         per = (n + ways - 1) // ways
         runs = [(a, min(a + per, n)) for a in range(0, n, per)]
 

@@ -454,4 +454,7 @@ def test_predict_labels_split_over_streams_is_bit_identical(dtype):
             p.mul_(1.01)
     again = model.predict_labels(x, torch.uint8, ways=2)          # first call after the change is a split one
     assert torch.equal(again, model.predict_labels(x, torch.uint8))
+    import copy
+    twin = copy.deepcopy(model)                                   # nothing unpicklable was hung on the module
+    assert torch.equal(twin.predict_labels(x, torch.uint8, ways=2), again)
 
