@@ -6,7 +6,7 @@
 N = 1, headline (`value`): BASELINE.json configs[1] -- ERFNet(20) inference, batch 16, bf16 activations with fp32
   accumulation, 3x512x1024 synthetic images resident in HBM, fused arg-max and the iouEval confusion histogram; one
   step = one batch through the whole pipeline, replayed from a HIP graph; the batch runs as two chains of launches on two
-  HIP streams (ERFNet.predict_labels(ways=2): images 0-7 and 8-15, bit-identical labels; `--infer-ways 1` = one chain).
+  HIP streams (ERFNet.evaluate_batch(ways=2): images 0-7 and 8-15, bit-identical labels and counts; `--infer-ways 1` = one chain).
   The same line carries
     "inference_one_chain" the same leg with one chain of launches (short leg),
     "training"       BASELINE.json configs[2]: the bf16 training step, batch 6 (its own steps / warm-up),
@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--infer-ways", type=int, default=2,
                     help="inference: cut the batch into this many runs of images, each a chain of launches on its own HIP stream "
-                         "(ERFNet.predict_labels(ways=...); bit-identical labels; 1 = one chain)")
+                         "(ERFNet.evaluate_batch(ways=...); bit-identical labels and counts; 1 = one chain)")
     ap.add_argument("--train-graph", action="store_true", help="N > 1: capture the training step (RCCL all-reduces included) into a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -262,8 +262,7 @@ def run_infer(args, world, rank, dev, dtype=None, steps=None, warmup=None, roofl
 
     def step():
         with torch.no_grad():
-            labels = model.predict_labels(x, torch.uint8, ways=args.infer_ways)
-            ev.addBatch(labels.unsqueeze(1), target)
+            model.evaluate_batch(x, target, ev, torch.uint8, ways=args.infer_ways)      # labels, then iouEval.addBatch
 
     step()                                    # packs weights, allocates the histogram
     torch.cuda.synchronize()

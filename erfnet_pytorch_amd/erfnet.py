@@ -293,7 +293,19 @@ class ERFNet(nn.Module):
                                                    label_dtype=label_dtype)
         return (labels, logits) if with_logits else labels
 
-    def _predict_labels_split(self, input, label_dtype, ways):
+    @torch.no_grad()
+    def evaluate_batch(self, input, target, evaluator, label_dtype=torch.uint8, ways=1):
+        """One step of the evaluation loop (eval/eval_iou.py:88-93): labels = model(input).max(1)[1], then
+        evaluator.addBatch(labels.unsqueeze(1), target).  With ways > 1 every chain of predict_labels(ways=...) counts its own
+        images as soon as its labels exist (the counters are integer atomics, so the order does not matter) instead of one
+        count over the whole batch after the chains have joined.  Returns the labels."""
+        if ways > 1 and input.shape[0] >= ways:
+            return self._predict_labels_split(input, label_dtype, int(ways), evaluator, target)
+        labels = self.predict_labels(input, label_dtype)
+        evaluator.addBatch(labels.unsqueeze(1), target)
+        return labels
+
+    def _predict_labels_split(self, input, label_dtype, ways, evaluator=None, target=None):
         code = self._code(input)
         # packed weights / folded affines are (re)built on the caller's stream BEFORE the chains fork: built inside one
         # chain they would be read by the others without any ordering
@@ -310,9 +322,15 @@ class ERFNet(nn.Module):
         per = (n + ways - 1) // ways
         runs = [(a, min(a + per, n)) for a in range(0, n, per)]
 
+        if evaluator is not None:
+            target = target.to(input.device)
+            evaluator.reserve(input.device)                              # counters exist before the chains fork
+
         def chain(a, b):
             x = self.encoder.forward_features_nhwc(input[a:b], code)
             self.decoder.forward_nhwc(x, want_logits=False, want_labels=True, label_dtype=label_dtype, labels_out=labels[a:b])
+            if evaluator is not None:
+                evaluator.addBatch(labels[a:b].unsqueeze(1), target[a:b])
 
         for (a, b), s in zip(runs[1:], side):
             s.wait_stream(cur)                 # the input, the label buffer and the packed weights are ready

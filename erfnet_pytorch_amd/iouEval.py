@@ -46,10 +46,16 @@ class iouEval:
         x, y = x.to(dev), y.to(dev)           # the reference moves both to the GPU when either is there (:27-29)
         if x.dim() == 4 and x.size(1) != 1 or y.dim() == 4 and y.size(1) != 1:
             return self._add_planes(x, y, dev)
+        self.reserve(dev)
+        ops.iou_hist_accumulate(x, y, self.nClasses, self._hist)
+
+    def reserve(self, dev):
+        """Allocates (and clears) the device counters for label-map inputs on the current stream.  addBatch does this by
+        itself; a caller that is about to count from several streams at once calls it first, on the stream they fork from."""
+        dev = torch.device(dev)
         if self._hist is None or self._hist.device != dev:
             self._flush()
             self._hist = torch.zeros(self.nClasses * self.nClasses + 1, dtype=torch.int64, device=dev)
-        ops.iou_hist_accumulate(x, y, self.nClasses, self._hist)
 
     def _add_planes(self, x, y, dev):
         """At least one input comes as N x nClasses x H x W planes (train/iouEval.py:32-46 `else` branches)."""

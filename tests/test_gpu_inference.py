@@ -458,3 +458,28 @@ def test_predict_labels_split_over_streams_is_bit_identical(dtype):
     twin = copy.deepcopy(model)                                   # nothing unpicklable was hung on the module
     assert torch.equal(twin.predict_labels(x, torch.uint8, ways=2), again)
 
+
+def test_evaluate_batch_counts_per_chain_equal_the_whole_batch_count():
+    """ERFNet.evaluate_batch (eval/eval_iou.py:88-93: labels, then iouEval.addBatch): with two chains every chain counts its own
+    images; labels and the confusion matrix equal the one-chain ones exactly, launched and replayed from a HIP graph."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.iouEval import iouEval
+    model = E.ERFNet(20)
+    model.load_state_dict(O.synthetic_state(O.erfnet_template(20)))
+    model = model.to(_dev()).eval()
+    model.compute_dtype = torch.bfloat16
+    x = S.synthetic_images(5, 64, 128, seed=21).to(_dev())
+    t = S.synthetic_labels(5, 64, 128, 20, seed=21).to(_dev())
+    ev1, ev2, ev3 = iouEval(20), iouEval(20), iouEval(20)
+    l1 = model.evaluate_batch(x, t, ev1)
+    l2 = model.evaluate_batch(x, t, ev2, ways=2)
+    assert torch.equal(l1, l2) and torch.equal(ev1.confusion(), ev2.confusion())
+    assert int(ev1.confusion().sum()) == 5 * 64 * 128
+    ev3.reserve(_dev())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        l3 = model.evaluate_batch(x, t, ev3, ways=2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(l3, l1) and torch.equal(ev3.confusion(), ev1.confusion())
+
