@@ -23,6 +23,9 @@ t = S.synthetic_labels(16, 512, 1024, 20, seed=1).to(dev)
 def build(ways):
     ev = iouEval(20)
     xs, ts = x.chunk(ways), t.chunk(ways)
+    if os.environ.get("SPLIT"):                       # e.g. SPLIT=10,6: unequal runs of images
+        sizes = [int(v) for v in os.environ["SPLIT"].split(",")]
+        xs, ts, ways = x.split(sizes), t.split(sizes), len(sizes)
     side = [torch.cuda.Stream() for _ in range(ways - 1)]
 
     def step():
