@@ -15,12 +15,19 @@ N = 1, headline (`value`): BASELINE.json configs[1] -- ERFNet(20) inference, bat
     "roofline_block" the same measurement priced per non_bottleneck_1d block against the block's algorithmic bytes
                      (x in, y out), which shows what the two-launch block spends above the one-pass model,
     "cpu_baseline"   the oracle's fp32 forward, b=1, on this box's host cores (eval_forwardTime protocol).
-N > 1 (launched by torch.distributed.run, one rank per GPU), headline: the data-parallel TRAINING step of configs[2]
+    "measured_peak"  what this GPU sustains on an MFMA-only loop (bf16, fp32) and on a streaming copy (erfnet_pytorch_amd/probe.py);
+                     every roofline object carries `frac_of_measured` beside `frac` (which is against the nominal peak).
+N > 1, headline: the data-parallel TRAINING step of configs[2]
   -- batch 6 per GPU, weighted cross-entropy, Adam, gradient all-reduce over RCCL inside the timed region ("weak"
-  scaling: per-GPU work fixed); the step is replayed from three HIP graphs with the all-reduces issued between them
-  (`--train-graph`: one graph with the all-reduces captured, `--no-graph`: kernel-by-kernel launches).  "inference" then holds the inference leg (independent shards per rank: the path has
-  no exchange step), "world_size" what the process group reports, and "allreduce" the time of each gradient bucket's
-  all-reduce alone.
+  scaling: per-GPU work fixed); the step is replayed from five HIP graphs (forward | three backward sections | Adam) with each
+  gradient bucket's asynchronous all-reduce issued right after the section that completes it, i.e. under the next section's
+  kernels (`--train-graph`: one graph with the all-reduces captured, `--no-graph`: kernel-by-kernel launches).  "inference"
+  then holds the inference leg (independent shards per rank: the path has no exchange step), "world_size" what the process
+  group reports, and "allreduce" the time of each gradient bucket's all-reduce alone plus `exposed_ms`, the step time with
+  the collectives minus the step time with them muted.
+  The N ranks come either from a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) or, when
+  `--gpus N` is given without that environment, from this script itself: the parent starts N fresh child processes of
+  bench.py before it touches the GPU, relays rank 0's JSON line and exits non-zero if any rank does.
 `--mode train` / `--mode infer` force one leg as the headline at any N.  Rank 0 prints exactly one JSON line.
 """
 from __future__ import annotations
@@ -37,7 +44,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FWD_FLOP_PER_IMG = 2 * 26_612_727_808            # 512x1024, 20 classes (53.225 GFLOP)
+HEAD_MAC_PER_CLASS = 16 * 256 * 512 * 4          # Decoder.output_conv at 512x1024, per class (167,772,160 MAC for 20)
 TRAIN_FLOP_PER_IMG = 2 * (3 * 26_612_727_808 - 46_006_272)
+
+
+def forward_flop(classes, height, width):
+    """Multiply-accumulate count of one ERFNet(classes) forward x 2: everything but the head scales with the area only."""
+    mac = 26_612_727_808 - 20 * HEAD_MAC_PER_CLASS + classes * HEAD_MAC_PER_CLASS
+    return 2.0 * mac * (height * width) / (512 * 1024)
 PEAK_BF16_TFLOPS = 2500.0                        # dense bf16 MFMA peak of MI355X
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -71,8 +85,50 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`--gpus N` (N > 1) without a launcher's environment: start N fresh ranks of this script, one per GPU.  Runs before
+    anything in this process touches the GPU (children are new processes, nothing is re-executed in place).  Rank 0's
+    stdout is relayed line by line; the exit status is the first non-zero one of the ranks; when one rank dies the others
+    are given a short grace period and then ended by PID."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if os.environ.get("ERF_BENCH_REHEARSAL") != "1":
+        have = torch.cuda.device_count()               # counting devices does not initialise the GPU
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=r == 0))
+    for line in procs[0].stdout:                       # ends when rank 0 closes its stdout
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        codes = [p.poll() for p in procs]
+        if deadline is None and any(c not in (None, 0) for c in codes):
+            deadline = time.time() + 20
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    for p in procs:
+        rc = rc or p.returncode
+    return rc
+
+
 def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n_gpus != world:
+        raise SystemExit(f"bench.py --gpus {n_gpus} but the process group has WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -147,15 +203,16 @@ def cpu_baseline(height, width, budget_s=20.0):
 
 
 def measured_traffic(kernel_prefix, pixels):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    """(HBM bytes per launch of the dominant kernel, file they come from): the newest committed rocprofv3 PMC passes
     (profiles/rNN_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch, mean over the kernel's
-    variants); only quoted when this run has the shape the counters were collected on."""
+    variants) -- a figure carried over from a profiled run of the same command, not measured in this run (the counters
+    need rocprofv3); only quoted when this run has the shape the counters were collected on."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not paths or pixels != 16 * 128 * 256:
-        return None
+        return None, None
     vals = [v for k, v in json.load(open(paths[-1])).items() if kernel_prefix in k]
-    return sum(vals) / len(vals) if vals else None
+    return (sum(vals) / len(vals) if vals else None), os.path.join("profiles", os.path.basename(paths[-1]))
 
 
 def roofline_infer(model, x, dtype_name):
@@ -227,9 +284,10 @@ def roofline_infer(model, x, dtype_name):
     avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * inner * len(plan))
     if dtype_name == "bf16":
         achieved = bytes_per_launch / avg_s / 1e9
-        traffic = measured_traffic("conv1d_pair_kernel<64,", n * hh * ww)
+        traffic, traffic_file = measured_traffic("conv1d_pair_kernel<64,", n * hh * ww)
         per_launch = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                      "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
+                      "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_from_profile": traffic_file,
+                      "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
                       "bytes_per_launch": bytes_per_launch, "flop_per_launch": flop, "mfma_tflops": flop / avg_s / 1e12}
         # The same time priced per BLOCK: a non_bottleneck_1d block needs x in and y out once (2 tensors); its two launches
         # move 5 (x, mid | mid, x again, y).  achieved = algorithmic block bytes / time of the block's two launches.
@@ -295,8 +353,7 @@ def run_infer(args, world, rank, dev, dtype=None, steps=None, warmup=None, roofl
                    "hip_graph": graph is not None, "streams": max(1, min(args.infer_ways, batch)), "synthetic_miou": miou},
     }
     if rank == 0:
-        flops = FWD_FLOP_PER_IMG * (args.height * args.width) / (512 * 1024)
-        res["model_tflops"] = res["value"] * flops / 1e12
+        res["model_tflops"] = res["value"] * forward_flop(args.classes, args.height, args.width) / 1e12
         if roofline and not args.no_roofline:
             res["roofline"], per_block = roofline_infer(model, x, args.dtype)
             if per_block is not None:
@@ -366,8 +423,39 @@ def free_gpu():
     torch.cuda.empty_cache()
 
 
+def add_measured_peaks(res, dev):
+    """`measured_peak` and a `frac_of_measured` beside every `frac`: the same achieved rate against what this GPU sustained on
+    the probe kernels in this very run (the nominal peaks are datasheet numbers the part does not reach under load)."""
+    from erfnet_pytorch_amd import probe
+    mp = probe.measured_peaks(dev)
+    res["measured_peak"] = mp
+    for key in ("roofline", "roofline_block"):
+        rf = res.get(key)
+        if not rf:
+            continue
+        if rf["bound"] == "hbm":
+            rf["frac_of_measured"] = rf["achieved"] / mp["hbm_copy_gbs"]
+            if "mfma_tflops" in rf:
+                rf["mfma_frac"] = rf["mfma_tflops"] / PEAK_BF16_TFLOPS
+                rf["mfma_frac_of_measured"] = rf["mfma_tflops"] / mp["mfma_bf16_tflops"]
+        else:
+            rf["frac_of_measured"] = rf["achieved"] / mp["mfma_f32_tflops"]
+    def price(leg, dtype):
+        if leg and "model_tflops" in leg:
+            peak, meas = (PEAK_BF16_TFLOPS, mp["mfma_bf16_tflops"]) if dtype == "bf16" else (PEAK_F32_TFLOPS, mp["mfma_f32_tflops"])
+            leg["mfma_frac"] = leg["model_tflops"] / peak
+            leg["mfma_frac_of_measured"] = leg["model_tflops"] / meas
+    price(res, res.get("dtype"))
+    for k in ("inference_one_chain", "training", "inference"):
+        price(res.get(k), (res.get(k) or {}).get("dtype"))
+    for k, leg in (res.get("fp32") or {}).items():
+        price(leg, "fp32")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and the package has no CPU path")
     world, rank, local = dist_setup(args.gpus)
@@ -408,6 +496,8 @@ def main():
         res["inference"] = leg(run_infer(args, world, rank, dev, steps=args.infer_steps, warmup=args.infer_warmup, roofline=False))
     res.setdefault("world_size", world)
     if rank == 0:
+        if not args.no_roofline and args.mode in ("auto", "infer", "train"):
+            add_measured_peaks(res, dev)
         if not args.no_cpu_baseline and world == 1 and args.mode != "multi":
             res["cpu_baseline"] = cpu_baseline(args.height, args.width)
         if os.environ.get("ERF_BENCH_REHEARSAL") == "1" and world > 1:

@@ -104,6 +104,7 @@ SIGNATURES = {
     "erf_adam_fused_arena_hyper": (I, [P, P, P, P, LL, P, D, D, D, D, D, P]),
     "erf_dropout2d_mask_many_counter": (I, [P, I, P, P, P, P]),
     "erf_sgd_fused_arena": (I, [P, P, P, LL, D, D, D, I, D, P]),
+    "erf_sgd_fused_arena_hyper": (I, [P, P, P, LL, P, D, I, D, P]),
     "erf_conv1d_dgrad": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "erf_downsampler_dgrad_packed_bytes": (c_size_t, [I, I, I]),
     "erf_downsampler_dgrad_pack": (I, [P, P, I, I, I, P]),
@@ -143,6 +144,9 @@ SIGNATURES = {
     "erf_pointwise_dgrad_pack": (I, [P, P, I, I, I, P]),
     "erf_pointwise_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
     "erf_pointwise_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
+    "erf_probe_mfma_flop": (LL, [I, I, I]),
+    "erf_probe_mfma": (I, [I, I, I, P, P, P]),
+    "erf_probe_copy": (I, [P, P, LL, I, P]),
     "erf_static_scratch_max_channels": (I, []),
     "erf_bn_stats_finalize_static": (I, [P, I, LL, I, P, P, P, P, F, F, P, P, P, P, P]),
 }

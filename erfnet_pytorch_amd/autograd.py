@@ -784,16 +784,41 @@ def erfnet_forward_loss(net, x, target, weight=None, group=None):
     return _HeadLossFn.apply(y, oc.weight, oc.bias, target, weight, group, oc)
 
 
-# ---- the same step cut at its two exchange points (a step replayed from HIP graphs with the collectives issued between them)
-def erfnet_forward_sums(net, x, target, weight=None):
+# ---- the same step cut at its exchange points (a step replayed from HIP graphs with the collectives issued between them)
+def _cut(y):
+    """A leaf that carries y's values (and the BatchNorm tail the next block's backward fuses): the autograd graph ends here,
+    so the backward pass can be run -- and captured -- one section at a time."""
+    d = y.detach().requires_grad_(True)
+    tail = getattr(y, "_erf_bn_tail", None)
+    if tail is not None:
+        d._erf_bn_tail = tail
+    return d
+
+
+def erfnet_forward_sums(net, x, target, weight=None, cuts=False):
     """First part of erfnet_forward_loss: the decoder's features (autograd graph attached) and this rank's
     (sum w*nll, sum w, ratio) of the fused output layer + loss, with NO exchange: the caller all-reduces the first two numbers.
-    Returns (features, sums, state for erfnet_backward_from_sums)."""
-    feats = encoder_forward(net.encoder, x, code=_compute_code(net, x))
-    y = feats
-    for layer in net.decoder.layers:
+    Returns (features, sums, state for erfnet_backward_from_sums).
+    cuts: the autograd graph is cut where the gradient buckets of dp.bucket_ranges end -- in front of the decoder and in
+    front of the 128-channel encoder stage (encoder.layers[6]) -- and state carries the (output, leaf) pairs, last section
+    first, for erfnet_backward_sections."""
+    enc, dec = net.encoder, net.decoder
+    enc.initial_block.__dict__["_erf_code"] = _compute_code(net, x)
+    y = block_forward(enc.initial_block, x)
+    joints = []
+    for i, layer in enumerate(enc.layers):
+        if cuts and i == 6:
+            leaf = _cut(y)
+            joints.append((y, leaf))
+            y = leaf
         y = block_forward(layer, y)
-    oc = net.decoder.output_conv
+    if cuts:
+        leaf = _cut(y)
+        joints.append((y, leaf))
+        y = leaf
+    for layer in dec.layers:
+        y = block_forward(layer, y)
+    oc = dec.output_conv
     w, b = oc.weight, oc.bias
     xh = ops.to_nhwc(y.detach())
     code, dev = ops.dt(xh), xh.device
@@ -809,13 +834,13 @@ def erfnet_forward_sums(net, x, target, weight=None):
     ws = _ws(size_query("erf_output_conv_ce_workspace_bytes", n, h, wd), dev)
     call("erf_output_conv_ce_fwd", xh.data_ptr(), packed.data_ptr(), bias.data_ptr(), target.data_ptr(), _p(wt), out3.data_ptr(),
          ws.data_ptr(), code, n, h, wd, nc, _stream())
-    return y, out3, (xh, w, bias, target, wt, packed, oc)
+    return y, out3, (xh, w, bias, target, wt, packed, oc, joints[::-1])
 
 
-def erfnet_backward_from_sums(y, sums, state):
-    """Second part: loss = sums[0] / sums[1] (the caller has summed both over the ranks) and the whole backward pass, the
-    output layer's by hand with the coefficient 1 / sums[1] that _HeadLossFn.backward derives from a unit loss gradient."""
-    xh, w, bias, target, wt, packed, oc = state
+def _head_backward(sums, state):
+    """loss = sums[0] / sums[1] (the caller has summed both over the ranks) and the output layer's backward by hand, with the
+    coefficient 1 / sums[1] that _HeadLossFn.backward derives from a unit loss gradient.  Returns (loss, d features)."""
+    xh, w, bias, target, wt, packed, oc = state[:7]
     code, dev = ops.dt(xh), xh.device
     n, h, wd, _ = xh.shape
     nc = w.shape[1]
@@ -828,8 +853,32 @@ def erfnet_backward_from_sums(y, sums, state):
     grads = _outconv_backward(oc, xh, w, patches)
     if grads[1] is not None:                             # no gradient arena attached: hand the output layer's gradients over
         oc.weight.grad, oc.bias.grad = grads[1], grads[2]
-    y.backward(grads[0])
+    return loss, grads[0]
+
+
+def erfnet_backward_from_sums(y, sums, state):
+    """Second part: the loss and the whole backward pass in one go (state from erfnet_forward_sums(cuts=False))."""
+    loss, g = _head_backward(sums, state)
+    y.backward(g)
     return loss
+
+
+def erfnet_backward_sections(y, sums, state):
+    """Second part, section by section (state from erfnet_forward_sums(cuts=True)): a generator that runs the head and the
+    decoder's backward, yields, runs the 128-channel encoder stage, yields, runs the rest and returns; every section ends
+    with its bias / weight-gradient reductions flushed, so the gradient bucket it completes may leave at the yield.  The
+    gradient crosses a cut as the very tensor the section's last kernel wrote (torch.autograd.grad hands it out without a
+    copy), which keeps the BatchNorm-backward hand-off between neighbouring blocks alive across the cut.  The first value
+    yielded is the loss tensor."""
+    loss, g = _head_backward(sums, state)
+    out = y
+    for k, (produced, leaf) in enumerate(state[7]):
+        (g,) = torch.autograd.grad([out], [leaf], [g])
+        flush_bias_sums()
+        yield loss if k == 0 else None
+        out = produced
+    out.backward(g)
+    flush_bias_sums()
 
 
 def erfnet_forward(net, x):

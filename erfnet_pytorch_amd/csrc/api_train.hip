@@ -256,6 +256,12 @@ int erf_sgd_fused_arena(float* params, const float* grads, float* momentum_buf, 
     return sgd_launch(params, grads, momentum_buf, n, lr, momentum, weight_decay, first_step, grad_scale, (hipStream_t)stream);
 }
 
+int erf_sgd_fused_arena_hyper(float* params, const float* grads, float* momentum_buf, long long n, const float* hyper,
+                              double momentum, int first_step, double grad_scale, void* stream) {
+    if (!params || !grads || !momentum_buf || !hyper) return ERF_EINVAL;
+    return sgd_hyper_launch(params, grads, momentum_buf, n, hyper, momentum, first_step, grad_scale, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ data gradients
 int erf_conv1d_dgrad(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual, int dtype,
                      int N, int H, int W, int C, int axis, int dilation, void* stream) {

@@ -48,6 +48,8 @@ int adam_launch(float* p, const float* g, float* m, float* v, long long n, doubl
                 double wd, int step, double gscale, hipStream_t stream);
 int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, double momentum, double wd, int first,
                double gscale, hipStream_t stream);
+int sgd_hyper_launch(float* p, const float* g, float* buf, long long n, const float* hyper, double momentum, int first,
+                     double gscale, hipStream_t stream);
 int patches_launch(const void* dl, int src_dtype, void* out, int dtype, int N, int H, int W, int nc, int ncp, int ld,
                    hipStream_t stream, int patch_edge = 2);
 int image_pad_launch(const void* x, int src_dtype, void* out, int dtype, int N, long long HW, int cpad, hipStream_t stream);

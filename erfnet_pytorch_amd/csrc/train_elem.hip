@@ -872,6 +872,29 @@ int sgd_launch(float* p, const float* g, float* buf, long long n, double lr, dou
     return erf_check_launch();
 }
 
+// SGD with the learning rate and the weight decay in device memory (hyper[0], hyper[1]): a captured step replays with
+// whatever values the schedule has stored there.  The arithmetic per element is sgd_kernel's.
+__global__ __launch_bounds__(256) void sgd_hyper_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                        long long n, const float* __restrict__ hyper, float momentum, int first,
+                                                        float gscale) {
+    const float lr = hyper[0], wd = hyper[1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;
+        const float bi = first ? gi : momentum * buf[i] + gi;
+        buf[i] = bi;
+        p[i] = pi - lr * bi;
+    }
+}
+
+int sgd_hyper_launch(float* p, const float* g, float* buf, long long n, const float* hyper, double momentum, int first,
+                     double gscale, hipStream_t stream) {
+    if (n <= 0) return ERF_EINVAL;
+    hipLaunchKernelGGL(sgd_hyper_kernel, dim3(ew_grid(n)), dim3(256), 0, stream, p, g, buf, n, hyper, (float)momentum, first,
+                       (float)gscale);
+    return erf_check_launch();
+}
+
 // --------------------------------------------------------------------------------------------
 // dlogits NCHW [N,nc,2H,2W] -> "patch" NHWC [N,H,W,ld] (channel = 4*class + phase, phase = 2a+b
 // the position inside the 2x2 output patch; channels >= 4*nc zero), the layout output_conv's

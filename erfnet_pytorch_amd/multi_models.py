@@ -21,13 +21,12 @@ __all__ = ["DownsamplerBlock_simplified", "non_bottleneck_1d", "Encoder", "Upsam
            "Decoder_depth", "Classifier", "Multi_models"]
 
 
+T = torch.ops.erfnet_mi355          # registered by torch_ops (imported by ops)
+
+
 def _concat(a, b):
     """torch.cat([a, b], 1) of the reference on NHWC maps of one dtype."""
-    n, h, w, ca = a.shape
-    cb = b.shape[3]
-    out = torch.empty((n, h, w, ca + cb), dtype=a.dtype, device=a.device)
-    call("erf_concat_channels", a.data_ptr(), ca, b.data_ptr(), cb, out.data_ptr(), ops.dt(a), n, h, w, _stream())
-    return out
+    return T.concat_channels(a, b)
 
 
 def _stream():
@@ -52,11 +51,7 @@ def _pack_conv3x3(w, code, cin_padded):
 
 
 def _conv3x3(x, packed, scale, shift, cout, stride, relu):
-    n, h, w, cin = x.shape
-    y = torch.empty((n, (h + stride - 1) // stride, (w + stride - 1) // stride, cout), dtype=x.dtype, device=x.device)
-    call("erf_conv3x3", x.data_ptr(), y.data_ptr(), packed.data_ptr(), 0 if scale is None else scale.data_ptr(),
-         0 if shift is None else shift.data_ptr(), ops.dt(x), n, h, w, cin, cout, stride, int(relu), _stream())
-    return y
+    return T.conv3x3(x, packed, scale, shift, cout, stride, relu)
 
 
 class DownsamplerBlock_simplified(_Block):
@@ -85,10 +80,7 @@ class DownsamplerBlock_simplified(_Block):
         n, c, h, w = image_nchw.shape
         if c != 3:
             raise ValueError("the first block takes 3-channel images")
-        img = image_nchw.contiguous()
-        x = torch.empty((n, h, w, 16), dtype=ops.tdtype(code), device=img.device)
-        call("erf_image_to_nhwc_channels", img.data_ptr(), ops.dt(img), x.data_ptr(), code, n, h, w, 16, _stream())
-        return self.forward_nhwc(x)
+        return self.forward_nhwc(T.image_to_nhwc_channels(image_nchw.contiguous(), code, 16))
 
     def forward_nhwc(self, x):
         n, h, w, _ = x.shape
@@ -96,10 +88,7 @@ class DownsamplerBlock_simplified(_Block):
             raise ValueError("DownsamplerBlock_simplified needs even H and W")
         c = self._cached(ops.dt(x))
         z = _conv3x3(x, c["w"], None, c["b"], self.noutput, 1, False)
-        y = torch.empty((n, h // 2, w // 2, self.noutput), dtype=x.dtype, device=x.device)
-        call("erf_maxpool2x2_affine", z.data_ptr(), y.data_ptr(), c["s"].data_ptr(), c["t"].data_ptr(), ops.dt(x), n, h, w,
-             self.noutput, 1, _stream())
-        return y
+        return T.maxpool2x2_affine(z, c["s"], c["t"], True)
 
 
 class Encoder(nn.Module):
@@ -176,10 +165,7 @@ class _SkipDecoder(nn.Module):
         n, h, w, _ = x.shape
         nc = self.upblock_3[0].out_channels
         packed, bias = self._head(ops.dt(x))
-        y = torch.empty((n, nc, 2 * h, 2 * w), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-        call("erf_convT2x2s2", x.data_ptr(), y.data_ptr(), packed.data_ptr(), bias.data_ptr(), int(out_f32), ops.dt(x), n, h, w,
-             32, nc, _stream())
-        return y
+        return T.convT2x2s2(x, packed, bias, nc, out_f32)
 
     def forward(self, input, shortcut_1, shortcut_2):
         _inference_only(self, input)
@@ -220,13 +206,7 @@ class Classifier(nn.Module):
     def forward_nhwc(self, x):
         packed, s, t, lw, lb = self._prep(ops.dt(x))
         y = _conv3x3(x, packed, s, t, 64, 2, True)           # conv + BatchNorm (folded) + ReLU; Dropout2d is the identity in eval
-        n, h, w, c = y.shape
-        feat = torch.empty((n, c), device=x.device)
-        call("erf_spatial_mean", y.data_ptr(), ops.dt(y), feat.data_ptr(), n, h, w, c, _stream())
-        out = torch.empty((n, self.linear.out_features), device=x.device)
-        call("erf_linear_fwd", feat.data_ptr(), lw.data_ptr(), lb.data_ptr(), out.data_ptr(), n, c, self.linear.out_features,
-             _stream())
-        return out
+        return T.linear(T.spatial_mean(y), lw, lb)
 
     def forward(self, input):
         _inference_only(self, input)

@@ -1,0 +1,64 @@
+"""Measured peaks of the GPU this process runs on: the denominators beside the nominal ones in bench.py's roofline objects.
+
+The reference times whole forward passes only (eval/eval_forwardTime.py:40-59); pricing a kernel against the hardware
+needs to know what the hardware sustains, which `erf_probe_mfma` / `erf_probe_copy` (csrc/probe.hip) measure:
+a matrix-instruction-only loop on every SIMD, and a 16-bytes-per-lane streaming copy.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import call, query
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _time_ms(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def mfma_peak(dtype_code: int, dev, workgroups: int = 0, iters: int = 20000, reps: int = 3):
+    """(sustained TFLOP/s, shader clock in GHz the loop ran at).  Default: four workgroups of 8 waves per CU, which the
+    kernel's registers and the 8 wave slots of a SIMD hold all at once, so every wave's loop spans the whole launch (a few
+    milliseconds) and the clock is the cycles one wave counted divided by the launch time."""
+    cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    workgroups = workgroups or 4 * cu
+    sink = torch.zeros(1, device=dev)
+    cycles = torch.zeros(1, dtype=torch.int64, device=dev)
+    flop = query("erf_probe_mfma_flop", dtype_code, workgroups, iters)
+    ms = _time_ms(lambda: call("erf_probe_mfma", dtype_code, workgroups, iters, sink.data_ptr(), cycles.data_ptr(), _stream()), reps)
+    loop_cycles = int(cycles.item())
+    rounds = max(1.0, workgroups / (4.0 * cu))                    # more than four per CU run in rounds
+    ghz = loop_cycles / (ms * 1e-3 / rounds) / 1e9
+    return flop / (ms * 1e-3) / 1e12, ghz
+
+
+def copy_peak(dev, nbytes: int = 1 << 30, reps: int = 5):
+    """Streaming copy rate in GB/s counting bytes read + bytes written (a 1 GiB buffer is far beyond the 256 MB
+    last-level cache).  The best of a few grid sizes."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    src.fill_(1)
+    best = 0.0
+    for wgs in (2048, 4096, 8192, 16384):
+        ms = _time_ms(lambda: call("erf_probe_copy", src.data_ptr(), dst.data_ptr(), nbytes, wgs, _stream()), reps)
+        best = max(best, 2.0 * nbytes / (ms * 1e-3) / 1e9)
+    return best
+
+
+def measured_peaks(dev):
+    bf16, ghz_b = mfma_peak(1, dev)
+    f32, ghz_f = mfma_peak(0, dev, iters=10000)
+    return {"mfma_bf16_tflops": bf16, "mfma_bf16_clock_ghz": ghz_b, "mfma_f32_tflops": f32, "mfma_f32_clock_ghz": ghz_f,
+            "hbm_copy_gbs": copy_peak(dev),
+            "how": "erf_probe_mfma: MFMA-only loop, 8 chains x 2 waves per SIMD on every CU; erf_probe_copy: 1 GiB, 16 B per lane, read + write bytes"}

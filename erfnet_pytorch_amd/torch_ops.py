@@ -111,7 +111,10 @@ def _nb1d_block(x, w1, w2, w3, w4, table, dilation):
     rc = query("erf_nb1d_block_infer", x.data_ptr(), y.data_ptr(), w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), w4.data_ptr(),
                table.data_ptr(), _dt(x), n, h, w, c, dilation, _stream())
     if rc == -2:
-        raise NotImplementedError("nb1d_block takes bf16, 16 or 64 channels, dilation 1 (erf_nb1d_block_infer); use conv1d_pair twice")
+        # a shape the one-launch kernel declines (other channel counts / dtypes, very large maps): the two pair launches, which
+        # decline to single launches themselves; table rows = [1, b1, s2, t2, 1, b3, s4, t4]
+        mid = _conv1d_pair(x, w1, table[1], w2, table[2], table[3], None, 1, True)
+        return _conv1d_pair(mid, w3, table[5], w4, table[6], table[7], x, dilation, True)
     if rc != 0:
         raise RuntimeError(f"erf_nb1d_block_infer failed with status {rc}")
     return y
@@ -227,6 +230,110 @@ def _pointwise(x, packed, bias, nc, out_f32):
 _register("pointwise(Tensor x, Tensor packed, Tensor? bias, int nc, bool out_f32) -> Tensor", _pointwise,
           lambda x, packed, bias, nc, out_f32: x.new_empty((x.shape[0], nc, x.shape[1], x.shape[2]),
                                                            dtype=torch.float32 if out_f32 else x.dtype))
+
+
+# ------------------------------------------------------------------------------------------------ multi-task variant (train/multi_models.py)
+def _conv3x3(x, packed, scale, shift, cout, stride, relu):
+    """3x3 convolution, padding 1, stride 1 or 2, + per-channel scale / shift (+ ReLU): DownsamplerBlock_simplified's and the
+    classifier's convolution (train/multi_models.py:23-36, :181-189)."""
+    _nhwc(x, "conv3x3")
+    n, h, w, cin = x.shape
+    y = torch.empty((n, (h + stride - 1) // stride, (w + stride - 1) // stride, cout), dtype=x.dtype, device=x.device)
+    call("erf_conv3x3", x.data_ptr(), y.data_ptr(), packed.data_ptr(), _p(scale), _p(shift), _dt(x), n, h, w, cin, cout, stride,
+         int(relu), _stream())
+    return y
+
+
+_register("conv3x3(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, int cout, int stride, bool relu) -> Tensor", _conv3x3,
+          lambda x, packed, scale, shift, cout, stride, relu: x.new_empty(
+              (x.shape[0], (x.shape[1] + stride - 1) // stride, (x.shape[2] + stride - 1) // stride, cout)))
+
+
+def _maxpool2x2_affine(z, scale, shift, relu):
+    """maxpool 2x2 -> BatchNorm (folded to scale / shift) -> ReLU (train/multi_models.py:32-35)."""
+    _nhwc(z, "maxpool2x2_affine")
+    n, h, w, c = z.shape
+    if (h | w) & 1:
+        raise ValueError("maxpool2x2_affine needs even H and W")
+    y = torch.empty((n, h // 2, w // 2, c), dtype=z.dtype, device=z.device)
+    call("erf_maxpool2x2_affine", z.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _dt(z), n, h, w, c, int(relu), _stream())
+    return y
+
+
+_register("maxpool2x2_affine(Tensor z, Tensor scale, Tensor shift, bool relu) -> Tensor", _maxpool2x2_affine,
+          lambda z, scale, shift, relu: z.new_empty((z.shape[0], z.shape[1] // 2, z.shape[2] // 2, z.shape[3])))
+
+
+def _concat_channels(a, b):
+    """torch.cat([a, b], 1) of the reference (train/multi_models.py:141,145) on NHWC maps of one dtype."""
+    _nhwc(a, "concat_channels")
+    _nhwc(b, "concat_channels")
+    if a.shape[:3] != b.shape[:3] or a.dtype != b.dtype:
+        raise ValueError("concat_channels: maps of one size and dtype")
+    n, h, w, ca = a.shape
+    cb = b.shape[3]
+    out = torch.empty((n, h, w, ca + cb), dtype=a.dtype, device=a.device)
+    call("erf_concat_channels", a.data_ptr(), ca, b.data_ptr(), cb, out.data_ptr(), _dt(a), n, h, w, _stream())
+    return out
+
+
+_register("concat_channels(Tensor a, Tensor b) -> Tensor", _concat_channels,
+          lambda a, b: a.new_empty((a.shape[0], a.shape[1], a.shape[2], a.shape[3] + b.shape[3])))
+
+
+def _convT2x2s2(x, packed, bias, nc, out_f32):
+    """ConvTranspose2d(Cin, nc, 2, stride 2) + bias -> NCHW maps (the regression decoders' head, train/multi_models.py:131,147)."""
+    _nhwc(x, "convT2x2s2")
+    n, h, w, cin = x.shape
+    y = torch.empty((n, nc, 2 * h, 2 * w), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    call("erf_convT2x2s2", x.data_ptr(), y.data_ptr(), packed.data_ptr(), bias.data_ptr(), int(out_f32), _dt(x), n, h, w, cin, nc, _stream())
+    return y
+
+
+_register("convT2x2s2(Tensor x, Tensor packed, Tensor bias, int nc, bool out_f32) -> Tensor", _convT2x2s2,
+          lambda x, packed, bias, nc, out_f32: x.new_empty((x.shape[0], nc, 2 * x.shape[1], 2 * x.shape[2]),
+                                                           dtype=torch.float32 if out_f32 else x.dtype))
+
+
+def _spatial_mean(y):
+    """Mean over H and W per image and channel -> fp32 [N, C] (train/multi_models.py:198-199)."""
+    _nhwc(y, "spatial_mean")
+    n, h, w, c = y.shape
+    feat = torch.empty((n, c), dtype=torch.float32, device=y.device)
+    call("erf_spatial_mean", y.data_ptr(), _dt(y), feat.data_ptr(), n, h, w, c, _stream())
+    return feat
+
+
+_register("spatial_mean(Tensor y) -> Tensor", _spatial_mean, lambda y: y.new_empty((y.shape[0], y.shape[3]), dtype=torch.float32))
+
+
+def _linear(feat, weight, bias):
+    """nn.Linear on fp32 features [N, C] -> [N, K] (train/multi_models.py:200, train/erfnet_imagenet.py:116)."""
+    if feat.dtype != torch.float32 or weight.dtype != torch.float32 or feat.dim() != 2 or weight.shape[1] != feat.shape[1]:
+        raise ValueError("linear: fp32 features [N, C] and weight [K, C]")
+    n, c = feat.shape
+    out = torch.empty((n, weight.shape[0]), dtype=torch.float32, device=feat.device)
+    call("erf_linear_fwd", feat.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, c, weight.shape[0], _stream())
+    return out
+
+
+_register("linear(Tensor feat, Tensor weight, Tensor bias) -> Tensor", _linear,
+          lambda feat, weight, bias: feat.new_empty((feat.shape[0], weight.shape[0])))
+
+
+def _image_to_nhwc_channels(image, code, channels):
+    """NCHW fp32 / bf16 image -> NHWC with `channels` zero-padded channels in the compute dtype."""
+    if image.dim() != 4 or not image.is_contiguous():
+        raise ValueError("image_to_nhwc_channels: contiguous NCHW image")
+    n, c, h, w = image.shape
+    x = torch.empty((n, h, w, channels), dtype=torch.bfloat16 if code == BF16 else torch.float32, device=image.device)
+    call("erf_image_to_nhwc_channels", image.data_ptr(), _dt(image), x.data_ptr(), code, n, h, w, channels, _stream())
+    return x
+
+
+_register("image_to_nhwc_channels(Tensor image, int code, int channels) -> Tensor", _image_to_nhwc_channels,
+          lambda image, code, channels: image.new_empty((image.shape[0], image.shape[2], image.shape[3], channels),
+                                                        dtype=torch.bfloat16 if code == BF16 else torch.float32))
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm / dropout pieces

@@ -106,9 +106,13 @@ class Trainer:
         group exercises the whole collective path -- hooks, side-stream ordering, waits -- on a single GPU).
         `graph`: step() captures the whole optimisation step (zero_grad .. Adam, collectives included) into a HIP graph
         the second time it sees an input shape and replays it from then on; the inputs are copied into the graph's
-        static buffers.  graph="segments": the step is cut at its two exchange points into three graphs (forward + local
-        loss sums | backward | Adam) and the loss and gradient all-reduces are issued between the replays like any
-        other collective -- no collective is ever captured, and the host still enqueues three launches instead of ~370.  Everything that changes from step to step lives on the device for this (dropout seed counter,
+        static buffers.  graph="segments": the step is cut at its exchange points into five graphs (forward + local
+        loss sums | head + decoder backward | 128-channel encoder stage backward | remaining backward | Adam); the loss
+        all-reduce is issued between the first two, and each gradient bucket's asynchronous all-reduce right after the
+        replay of the section that completes it, so that it runs under the next section's kernels (`overlap=False`: all
+        three after the last section); Adam waits for them.  No collective is ever captured, and the host enqueues five
+        graph launches instead of ~370 kernels.  In graph modes the returned loss is a copy, the returned logits (if
+        any) alias a static buffer the next step overwrites.  Everything that changes from step to step lives on the device for this (dropout seed counter,
         Adam's step count and learning rate), graph or not, so both ways of running give the same bits."""
         self.model = model
         self.only_encode = only_encode
@@ -121,6 +125,7 @@ class Trainer:
         self._step_host = 0
         self.collective = world_size > 1 or (force_collectives and group is not None)
         self.overlap = overlap and self.collective
+        self.mute_collectives = False                   # timing aid (segments mode): replay the graphs, issue no all-reduce
         dev = next(model.parameters()).device
         self.dev = dev
         self.weight = None if class_weights is None else torch.tensor(class_weights, dtype=torch.float32, device=dev)
@@ -253,7 +258,12 @@ class Trainer:
         self._sync_lr()
         if not self.use_graph or self._host_masks():
             return self._step_eager(images, targets)
-        key = (tuple(images.shape), images.dtype, tuple(targets.shape), getattr(self.model, "compute_dtype", None))
+        # betas, eps, weight decay and the class weights are constants of the captured launches: part of the key, and graphs
+        # captured with other values are dropped (their private pools hold a whole step's activations)
+        hyper = (tuple(self.betas), float(self.eps), float(self.wd), None if self.weight is None else self.weight.data_ptr())
+        key = (tuple(images.shape), images.dtype, tuple(targets.shape), getattr(self.model, "compute_dtype", None), hyper)
+        for stale in [k for k in self._graphs if k[4] != hyper]:
+            del self._graphs[stale]
         entry = self._graphs.get(key)
         if entry is None:
             if key not in self._seen:                                 # first sight of a shape: run it eagerly (sizes caches, workspaces)
@@ -265,17 +275,22 @@ class Trainer:
         gt.copy_(targets)
         if self.segments:
             import torch.distributed as dist
-            g1, g2, g3, sums = graph
+            g1, sections, g3, sums = graph
+            quiet = self.mute_collectives
             g1.replay()
-            dist.all_reduce(sums[:2], group=self.group)               # (sum w*nll, sum w) over the global batch
-            g2.replay()
-            for lo, hi in self.buckets:
-                dist.all_reduce(self.gflat[lo:hi], group=self.group)
+            if not quiet:
+                dist.all_reduce(sums[:2], group=self.group)           # (sum w*nll, sum w) over the global batch
+            for i, g2 in enumerate(sections):
+                g2.replay()
+                if self.overlap and not quiet:                        # bucket i is complete: it travels under section i + 1
+                    self._launch_bucket(i)
+            if not quiet:
+                self._reduce_gradients()                              # (all buckets now if not overlapped) + wait
             g3.replay()
         else:
             graph.replay()
         self._after_replayed_step()
-        return loss, outputs
+        return loss.clone(), outputs
 
     def _host_masks(self):
         """Forced dropout masks (a test hook) that live in host memory would be uploaded inside the step: not capturable."""
@@ -302,30 +317,38 @@ class Trainer:
         return entry
 
     def _capture_segments(self, key, images, targets):
-        """Three graphs around the two exchange points of a step; see __init__.  The capture itself launches nothing and
-        issues no collective (the first, eager, step of this shape has already run them once)."""
+        """Five graphs around the exchange points of a step; see __init__.  The capture itself launches nothing and
+        issues no collective (the first, eager, step of this shape has already run them once).  The backward pass is cut
+        where the gradient buckets end (autograd.erfnet_backward_sections), one graph per bucket."""
         gx, gt = images.clone(), targets.clone()
         torch.cuda.synchronize()
         host = (self._step_host, self._epoch[0])
-        overlap, self.overlap = self.overlap, False                   # the bucket hooks stay silent: buckets go out between g2 and g3
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        overlap, self.overlap = self.overlap, False                   # the bucket hooks stay silent: buckets go out between the graphs
+        g1, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        sections = [torch.cuda.CUDAGraph() for _ in self.buckets]
         try:
             with _NoCollection():
                 with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                     self.zero_grad()
                     self._refresh_packed(gx)
                     _prepare_masks(self.model, gx, self._seed_state)
-                    feats, sums, state = ag.erfnet_forward_sums(self.model, gx, gt, self.weight)
+                    feats, sums, state = ag.erfnet_forward_sums(self.model, gx, gt, self.weight, cuts=True)
                     _flush_batch_counters(self._counted)
-                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
-                    loss = ag.erfnet_backward_from_sums(feats, sums, state).detach()
-                    ag.flush_bias_sums()
+                walk = ag.erfnet_backward_sections(feats, sums, state)
+                loss = None
+                for i, g2 in enumerate(sections):
+                    with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                        got = next(walk, None)
+                        if i == 0:
+                            loss = got.detach()
+                if next(walk, "done") != "done":
+                    raise RuntimeError("the backward pass has more sections than gradient buckets")
                 with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode="thread_local"):
                     self.optimizer_step()
         finally:
             self.overlap = overlap
         self._step_host, self._epoch[0] = host
-        entry = ((g1, g2, g3, sums), gx, gt, loss, None)
+        entry = ((g1, sections, g3, sums), gx, gt, loss, None)
         self._graphs[key] = entry
         return entry
 
@@ -393,6 +416,7 @@ class Trainer:
         if group.get("amsgrad") or group.get("maximize"):
             raise ValueError("amsgrad / maximize are not part of the reference recipe and are not supported")
         self.lr, self.betas, self.eps, self.wd = group["lr"], tuple(group["betas"]), group["eps"], group["weight_decay"]
+        self._graphs.clear()                                          # captured steps hold the old betas / eps / weight decay
         steps = set()
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
@@ -434,10 +458,11 @@ class ArenaSGD:
     over the ranks (RCCL) in one all-reduce before one fused SGD launch."""
 
     def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=1e-4, group=None, world_size=1, graph=False):
-        """`graph` (one GPU): from the third step with one input shape and learning rate on, the whole step is replayed from a
-        HIP graph (the step is launch-bound at 224x224).  The Dropout2d seed counter lives on the device in both modes, so
-        replayed and launched steps draw the same masks; the learning rate is a constant of the captured launch (a new
-        value is captured anew)."""
+        """`graph` (one GPU): from the third step with one input shape on, the whole step is replayed from a HIP graph (the
+        step is launch-bound at 224x224).  The Dropout2d seed counter, the learning rate and the weight decay live on the
+        device in both modes (imagenet/main.py:276-286 changes the last two from epoch to epoch: assign `.lr` / `.wd`
+        and the next step, replayed or launched, uses the new values); the momentum is a constant of the captured launch
+        and part of the graph key."""
         self.model, self.lr, self.momentum, self.wd = model, lr, momentum, weight_decay
         self.group, self.world = group, world_size
         self.step_count = 0
@@ -447,6 +472,8 @@ class ArenaSGD:
         self.use_graph = bool(graph) and world_size == 1
         self._graphs, self._seen = {}, set()
         self._seed_state = ag.new_seed_state(dev)
+        self._hyper = torch.tensor([lr, weight_decay], dtype=torch.float32, device=dev)
+        self._hyper_host = (float(lr), float(weight_decay))
         total = sum(p.numel() for _, p in named)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
         self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -479,10 +506,17 @@ class ArenaSGD:
         for p, v in self._views:
             p.grad = v                                  # autograd accumulates in place into the arena
 
+    def _sync_hyper(self):
+        now = (float(self.lr), float(self.wd))
+        if now != self._hyper_host:                                   # the schedule moved lr / wd: one small upload, no new capture
+            self._hyper.copy_(torch.tensor(now, dtype=torch.float32))
+            self._hyper_host = now
+
     def step(self, images, targets):
+        self._sync_hyper()
         if not self.use_graph or self.step_count == 0:                # the first step of a run also initialises the momentum buffers
             return self._step_eager(images, targets)
-        key = (tuple(images.shape), images.dtype, tuple(targets.shape), getattr(self.model, "compute_dtype", None), float(self.lr))
+        key = (tuple(images.shape), images.dtype, tuple(targets.shape), getattr(self.model, "compute_dtype", None), float(self.momentum))
         entry = self._graphs.get(key)
         if entry is None:
             if key not in self._seen:                                 # first sight: run it eagerly (sizes caches, workspaces)
@@ -519,9 +553,8 @@ class ArenaSGD:
             dist.all_reduce(self.gflat, group=self.group)
         from . import ops
         ops.bump_param_epoch()
-        call("erf_sgd_fused_arena", self.flat.data_ptr(), self.gflat.data_ptr(), self.buf.data_ptr(), self.flat.numel(),
-             float(self.lr), float(self.momentum), float(self.wd), int(self.step_count == 0), 1.0,
-             ops._stream())
+        call("erf_sgd_fused_arena_hyper", self.flat.data_ptr(), self.gflat.data_ptr(), self.buf.data_ptr(), self.flat.numel(),
+             self._hyper.data_ptr(), float(self.momentum), int(self.step_count == 0), 1.0, ops._stream())
         self.step_count += 1
         return loss.detach(), outputs.detach()
 
@@ -568,7 +601,27 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     value = world * batch * args.steps / elapsed
     extra = {"world_size": dist.get_world_size(group) if world > 1 else 1}
     if tr.collective:
-        extra["allreduce"] = tr.time_buckets(barrier=lambda: barrier(world), reduce_max=lambda v: max_over_ranks(v, world, dev))
+        final_loss = float(loss)
+        ar = tr.time_buckets(barrier=lambda: barrier(world), reduce_max=lambda v: max_over_ranks(v, world, dev))
+        if tr.segments:
+            # what the collectives cost the step: the same replays with every all-reduce muted (each rank then steps on its own
+            # gradients; nothing after this uses the parameters)
+            tr.mute_collectives = True
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            barrier(world)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            barrier(world)
+            muted = max_over_ranks(time.perf_counter() - t1, world, dev)
+            tr.mute_collectives = False
+            ar["step_ms_without_collectives"] = 1e3 * muted / args.steps
+            ar["exposed_ms"] = 1e3 * (elapsed - muted) / args.steps
+        extra["allreduce"] = ar
+        loss = torch.tensor(final_loss)
     return {
         **extra,
         "metric": "img/s ERFNet 512x1024: bf16 inference (1 GPU) + training (1/2/4/8 MI355X)",

@@ -227,6 +227,10 @@ int erf_adam_fused_arena_hyper(float* params, const float* grads, float* exp_avg
                                double beta1, double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 int erf_sgd_fused_arena(float* params, const float* grads, float* momentum_buf, long long n, double lr, double momentum,
                         double weight_decay, int first_step, double grad_scale, void* stream);
+/* The same update with the learning rate and the weight decay read from device memory (hyper[0], hyper[1]): one captured
+ * step serves every value of imagenet/main.py:276-286's schedule (lr * 0.95^(epoch-15), weight decay dropped to 0). */
+int erf_sgd_fused_arena_hyper(float* params, const float* grads, float* momentum_buf, long long n, const float* hyper,
+                              double momentum, int first_step, double grad_scale, void* stream);
 
 /* ---- batched weight re-packing (no counterpart in the reference: torch re-reads the fp32 parameters in place) ----
  * A training step re-packs every weight after the optimiser update.  Between erf_pack_record_begin(host_table,
@@ -405,6 +409,15 @@ int erf_maxpool2_avgpool_bwd(const void* x, const float* dfeat, void* dx, int dt
 int erf_linear_fwd(const float* f, const float* w, const float* b, float* y, int N, int C, int K, void* stream);
 int erf_linear_bwd(const float* f, const float* w, const float* dy, float* df, float* dw, float* db, int N, int C, int K,
                    void* stream);
+
+/* ---- peak probes (no counterpart in the reference, which times whole forward passes only: eval/eval_forwardTime.py:40-59) ----
+ * What this part sustains on the two resources the roofline fractions are priced against.  erf_probe_mfma: a
+ * matrix-instruction-only loop (dtype 1: v_mfma_f32_16x16x32_bf16, 0: v_mfma_f32_16x16x4_f32; `workgroups` of 8 waves, `iters`
+ * trips of 8 independent chains per wave); erf_probe_mfma_flop: the flop such a launch executes; cycles[0] receives the
+ * shader-clock cycles of one wave's loop.  erf_probe_copy: streaming copy of `bytes` (multiple of 16) by `workgroups` x 256 lanes. */
+long long erf_probe_mfma_flop(int dtype, int workgroups, int iters);
+int erf_probe_mfma(int dtype, int workgroups, int iters, float* sink, long long* cycles, void* stream);
+int erf_probe_copy(const void* src, void* dst, long long bytes, int workgroups, void* stream);
 
 /* ---- the one entry point that allocates nothing and takes no workspace ------------------------------------------
  * No counterpart in the reference.  It is for callers that cannot allocate device memory: code under HIP-graph

@@ -127,3 +127,32 @@ def test_sgd_step_replayed_from_a_graph_equals_the_launched_step():
     assert res[0][0] == res[1][0]
     for a, b in zip(res[0][1:], res[1][1:]):
         assert np.array_equal(a, b)
+
+
+def test_sgd_schedule_changes_reach_the_replayed_step_without_a_new_capture():
+    """imagenet/main.py:276-286 moves the learning rate every epoch and drops the weight decay at a milestone.  Both are
+    read from device memory by the update kernel, so ONE captured graph serves every value: seven steps with lr and wd
+    changed between replays must equal the launched run bit for bit, and the graph table must keep its single entry."""
+    from erfnet_pytorch_amd.trainer import ArenaSGD
+    x = S.synthetic_images(2, 224, 224, seed=62).to(DEV)
+    t = torch.randint(0, 1000, (2,), generator=torch.Generator().manual_seed(6)).to(DEV)
+    schedule = {3: (0.05 * 0.95, 1e-4), 4: (0.05 * 0.95 ** 2, 0.0), 6: (0.05 * 0.95 ** 3, 0.0)}
+    res = []
+    for graph in (False, True):
+        torch.manual_seed(78)
+        m, _ = _model()
+        m.train()
+        m.compute_dtype = torch.bfloat16
+        tr = ArenaSGD(m, lr=0.05, momentum=0.9, weight_decay=1e-4, graph=graph)
+        losses = []
+        for i in range(7):
+            if i in schedule:
+                tr.lr, tr.wd = schedule[i]
+            loss, _ = tr.step(x, t)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert len(tr._graphs) == (1 if graph else 0)
+        res.append((losses, tr.flat.cpu().numpy().copy(), tr.buf.cpu().numpy().copy()))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)

@@ -296,7 +296,7 @@ def test_full_net_bf16_vs_golden(nc, tags):
 @pytest.mark.parametrize("nc,shape", [(20, (16, 512, 1024)), (6, (8, 1024, 2048))])
 def test_full_size_properties(nc, shape):
     """BASELINE configs[1] (batch 16, 3x512x1024, 20 classes) and configs[4] (batch 8, 3x1024x2048, 6 classes) at their
-    full sizes (the oracle takes seconds per image there), through properties
+    full sizes, through properties
     that do not depend on the size: fused labels == arg-max of the logits path bit for bit, images of a batch are
     independent (same result alone and in a batch), the confusion matrix counts every pixel once and equals the
     histogram of (label, prediction) pairs computed by torch."""
@@ -323,6 +323,70 @@ def test_full_size_properties(nc, shape):
     assert int(conf.sum()) == n * h * w
     ref = torch.bincount((target[:, 0].long() * nc + labels.long()).reshape(-1), minlength=nc * nc).reshape(nc, nc).cpu()
     assert torch.equal(conf.reshape(nc, nc).cpu().long(), ref)
+
+
+def _oracle_labels_and_margin(ref):
+    top2 = ref.topk(2, dim=1).values
+    return ref.max(1)[1], top2[:, 0] - top2[:, 1], float(ref.abs().max())
+
+
+@pytest.mark.parametrize("nc,batch,h,w,picks", [(20, 16, 512, 1024, (0, 15)), (6, 8, 1024, 2048, (7,))])
+def test_full_size_against_the_oracle(nc, batch, h, w, picks):
+    """BASELINE configs[1] / configs[4] at their full sizes against the CPU oracle (eval/eval_iou.py:88-93: forward, arg-max,
+    iouEval.addBatch), end to end through the kernels and tilings the benchmark runs: the whole-row d = 16 kernel, the
+    producer/consumer pair kernel with several tiles per workgroup, the 128-pixel tilings, the one-launch 16-channel blocks.
+    fp32 (a batch of the picked images): logits within 1e-4 of the largest logit, labels exact wherever the oracle's top-2
+    margin exceeds twice that, fewer than 1e-3 of the pixels differ.  bf16 (the full benchmark batch, picked images compared):
+    logits within the stated 6e-2, labels exact where the margin exceeds twice that.  iouEval counts on OUR labels equal the
+    oracle's counting of the same labels exactly, through evaluate_batch with one and with two chains of launches."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd.iouEval import iouEval
+    sd = O.synthetic_state(O.erfnet_template(nc))
+    model = E.ERFNet(nc)
+    model.load_state_dict(sd)
+    model = model.to(_dev()).eval()
+    x = S.synthetic_images(batch, h, w, seed=31)
+    target = S.synthetic_labels(batch, h, w, nc, seed=32)
+    idx = list(picks)
+    with torch.no_grad():
+        ref = O.erfnet(sd, x[idx])
+    gold, margin, amax = _oracle_labels_and_margin(ref)
+
+    # fp32, the picked images as one batch
+    xs = x[idx].contiguous().to(_dev())
+    with torch.no_grad():
+        y = model(xs).cpu()
+        lab = model.predict_labels(xs).cpu()
+    assert (y - ref).abs().max().item() <= FP32_TOL * amax
+    assert torch.equal(lab, y.max(1)[1])
+    decided = margin > 2 * FP32_TOL * amax
+    assert torch.equal(lab[decided], gold[decided])
+    assert (lab != gold).float().mean().item() < 1e-3
+    ev = iouEval(nc)
+    ev.addBatch(lab.unsqueeze(1).to(_dev()), target[idx].to(_dev()))
+    tp, fp, fn = O.iou_counts(lab.unsqueeze(1), target[idx], nc)
+    assert torch.equal(ev.tp, tp) and torch.equal(ev.fp, fp) and torch.equal(ev.fn, fn)
+    del y
+
+    # bf16, the whole benchmark batch
+    model.compute_dtype = torch.bfloat16
+    xd, td = x.to(_dev()), target.to(_dev())
+    ev1, ev2 = iouEval(nc), iouEval(nc)
+    with torch.no_grad():
+        yb = model(xd[idx].contiguous()).cpu()
+        l1 = model.evaluate_batch(xd, td, ev1, torch.uint8)
+        l2 = model.evaluate_batch(xd, td, ev2, torch.uint8, ways=2)
+    assert torch.equal(l1, l2) and torch.equal(ev1.confusion(), ev2.confusion())
+    assert (yb - ref).abs().max().item() <= BF16_LOGIT_TOL * amax
+    labb = l1.cpu()[idx].long()
+    assert torch.equal(labb, yb.max(1)[1])                         # images are independent: batch of 16 == batch of the picks
+    decided = margin > 2 * BF16_LOGIT_TOL * amax
+    assert decided.float().mean().item() > 0.05
+    assert torch.equal(labb[decided], gold[decided])
+    assert (labb == gold).float().mean().item() > 0.90
+    tp, fp, fn = O.iou_counts(l1.cpu().long().unsqueeze(1), target, nc)
+    for e in (ev1, ev2):
+        assert torch.equal(e.tp, tp) and torch.equal(e.fp, fp) and torch.equal(e.fn, fn)
 
 
 def test_iou_eval_exact_vs_golden_and_oracle():

@@ -30,6 +30,13 @@ def _samples(dev, dtype=torch.bfloat16):
         "upsampler": ((x64, pk, f(16), f(16), 16, True), [((2, 16, 32, 16), dtype)]),
         "output_conv": ((t(2, 8, 16, 16), pk, f(20), 20, True, True, 1), [((2, 20, 16, 32), torch.float32), ((2, 16, 32), torch.uint8)]),
         "pointwise": ((t(2, 8, 16, 128), pk, f(20), 20, True), [((2, 20, 8, 16), torch.float32)]),
+        "conv3x3": ((x64, pk, f(64), f(64), 64, 2, True), [((2, 4, 8, 64), dtype)]),
+        "maxpool2x2_affine": ((x64, f(64), f(64), True), [((2, 4, 8, 64), dtype)]),
+        "concat_channels": ((x64, t(2, 8, 16, 16)), [((2, 8, 16, 80), dtype)]),
+        "convT2x2s2": ((t(2, 8, 16, 32), pk, f(1), 1, True), [((2, 1, 16, 32), torch.float32)]),
+        "spatial_mean": ((x64,), [((2, 64), torch.float32)]),
+        "linear": ((t(2, 64, dt=torch.float32), t(14, 64, dt=torch.float32), f(14)), [((2, 14), torch.float32)]),
+        "image_to_nhwc_channels": ((t(2, 3, 8, 16, dt=torch.float32), BF16, 16), [((2, 8, 16, 16), torch.bfloat16)]),
         "bn_apply": ((x64, f(64), f(64), f(64), x64, t(2, 64, dt=torch.float32), True), [((2, 8, 16, 64), dtype)]),
         "channel_sum": ((x64,), [((64,), torch.float32)]),
         "dropout2d_mask": ((x64, 2, 64, 0.3, -5), [((2, 64), torch.float32)]),

@@ -40,6 +40,11 @@ def test_single_gpu_line_has_every_leg():
     assert "traffic" in rf and rf["avg_launch_us"] > 0
     rb = d["roofline_block"]
     assert rb["algorithmic_bytes_per_block"] * 2.5 == rb["launch_bytes_per_block"] and 0 < rb["frac"] < rf["frac"]
+    assert rf["traffic_from_profile"] is None or rf["traffic_from_profile"].startswith("profiles/")
+    mp = d["measured_peak"]
+    assert mp["mfma_bf16_tflops"] > 100 and mp["mfma_f32_tflops"] > 10 and mp["hbm_copy_gbs"] > 500
+    assert abs(rf["frac_of_measured"] - rf["achieved"] / mp["hbm_copy_gbs"]) < 1e-9 and "frac_of_measured" in rb
+    assert abs(d["mfma_frac"] - d["model_tflops"] / 2500.0) < 1e-9 and d["mfma_frac_of_measured"] > d["mfma_frac"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     tr = d["training"]
@@ -49,18 +54,36 @@ def test_single_gpu_line_has_every_leg():
     assert fp["inference"]["dtype"] == "fp32" and fp["training"]["dtype"] == "fp32" and fp["training"]["value"] > 0
 
 
-def test_two_rank_line_reports_training_as_the_headline(tmp_path):
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+BENCH_ARGS_2 = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--infer-steps", "2", "--infer-warmup", "1", "--height", "64",
+                "--width", "128", "--train-batch", "2", "--batch", "2"]
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_two_rank_line_reports_training_as_the_headline(tmp_path, launcher):
+    """`python bench.py --gpus 2` starts its two ranks itself (no launcher environment); under torch.distributed.run it joins
+    the ranks it is given.  Either way: n_gpus == world_size == 2 and the gradient buckets travel under the backward pass."""
     env = dict(os.environ, ERF_BENCH_REHEARSAL="1", ERF_BENCH_REHEARSAL_LIMIT="200")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--infer-steps", "2",
-           "--infer-warmup", "1", "--height", "64", "--width", "128", "--train-batch", "2", "--batch", "2"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + BENCH_ARGS_2
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + BENCH_ARGS_2
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert BASE_KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert "training step" in d["config"]["workload"] and d["config"]["global_batch"] == 4
-    assert d["config"]["hip_graph"] == "segments"             # three graphs, the collectives between their replays
+    assert d["config"]["hip_graph"] == "segments"             # five graphs, the collectives between their replays
     assert abs(d["value"] - 2 * 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert "REHEARSAL" in d["data"]
     inf = d["inference"]
@@ -68,4 +91,13 @@ def test_two_rank_line_reports_training_as_the_headline(tmp_path):
     ar = d["allreduce"]
     assert ar["ranks"] == 2 and len(ar["buckets"]) == 3 and all(b["ms"] > 0 and b["bytes"] == 4 * b["elements"] for b in ar["buckets"])
     assert sum(b["elements"] for b in ar["buckets"]) <= 2_066_836
+    assert ar["overlapped_with_backward"] is True and "exposed_ms" in ar and ar["step_ms_without_collectives"] > 0
     assert "cpu_baseline" not in d
+
+
+def test_gpus_flag_must_match_the_process_group():
+    """A launcher environment that disagrees with --gpus is an error, not a silent one-rank run."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -62,3 +62,52 @@ def test_static_scratch_entry_point_rejects_sizes_beyond_its_array():
                   v[3].data_ptr(), 0.1, 1e-3, v[4].data_ptr(), v[5].data_ptr(), v[6].data_ptr(), v[7].data_ptr(), ops._stream())
     torch.cuda.synchronize()
     assert all(float(t.abs().sum()) == 0 for t in v[2:])          # nothing was launched
+
+
+_CAPTURE_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from erfnet_pytorch_amd import _lib, ops
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+c = 64
+g = torch.Generator().manual_seed(3)
+z = torch.randn(2, 16, 24, c, generator=g).to(dev)
+gamma, beta = torch.rand(c, generator=g).to(dev) + 0.5, torch.randn(c, generator=g).to(dev)
+rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+outs = [torch.zeros(c, device=dev) for _ in range(4)]
+ws = torch.empty(_lib.query("erf_bn_workspace_bytes", c), dtype=torch.uint8, device=dev)
+def args(rm_, rv_, o):
+    return [z.data_ptr(), ops.dt(z), z.numel() // c, c, gamma.data_ptr(), beta.data_ptr(), rm_.data_ptr(), rv_.data_ptr(), 0.1, 1e-3] + [t.data_ptr() for t in o]
+if {warm}:
+    _lib.call("erf_bn_stats_finalize_static", *args(rm.clone(), rv.clone(), [t.clone() for t in outs]), ops._stream())
+    torch.cuda.synchronize()
+side = torch.cuda.Stream()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+    _lib.call("erf_bn_stats_finalize_static", *args(rm, rv, outs), ops._stream())
+for rep in range(2):
+    z.copy_(torch.randn(2, 16, 24, c, generator=g) * (rep + 1.5))
+    rm.zero_(); rv.fill_(1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    rm2, rv2 = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    ref = [torch.zeros(c, device=dev) for _ in range(4)]
+    _lib.call("erf_bn_stats_finalize", *args(rm2, rv2, ref), ws.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs + [rm, rv], ref + [rm2, rv2])), rep
+print("CAPTURE-OK")
+"""
+
+
+@pytest.mark.parametrize("warm", [True, False])
+def test_static_scratch_entry_point_under_graph_capture(warm):
+    """The advertised caller: the call captured into a HIP graph and replayed twice on different inputs, bit-identical to the
+    workspace entry point -- once after a warm call outside the capture, once as the library's very first call on the device
+    (a fresh process: the per-device symbol lookup then happens while the stream is capturing)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_SCRIPT.format(root=root, warm=warm)], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "CAPTURE-OK" in r.stdout, r.stderr[-2000:]
