@@ -10,6 +10,8 @@ N = 1, headline (`value`): BASELINE.json configs[1] -- ERFNet(20) inference, bat
   The same line carries
     "inference_one_chain" the same leg with one chain of launches (short leg),
     "training"       BASELINE.json configs[2]: the bf16 training step, batch 6 (its own steps / warm-up),
+    "inference_with_h2d" the headline pipeline fed from pinned HOST memory: uint8 images on a copy stream, double-buffered,
+                     ToTensor()'s / 255 applied by the initial block on load (PCIe-inclusive; never `value`),
     "fp32"           {"inference", "training"}: the same two legs with fp32 storage (short legs),
     "roofline"       the dominant kernel alone (full-batch launches, one chain), timed here with events on the launch stream,
     "roofline_block" the same measurement priced per non_bottleneck_1d block against the block's algorithmic bytes
@@ -361,6 +363,63 @@ def run_infer(args, world, rank, dev, dtype=None, steps=None, warmup=None, roofl
     return res
 
 
+def run_infer_h2d(args, dev, steps, warmup):
+    """The inference pipeline fed from HOST memory, as an evaluation loop is (eval/eval_iou.py:84-93: the loader hands over
+    decoded 8-bit images): every batch travels as uint8 [N,3,H,W] from pinned host memory on a copy stream into one of two
+    device buffers while the previous batch computes (the initial block applies ToTensor()'s / 255 on load), labels and the
+    iouEval histogram as in the headline.  Reported beside the headline, never as `value`."""
+    from erfnet_pytorch_amd.iouEval import iouEval
+    batch = args.batch or 16
+    model = build_model(dev, args.dtype, args.classes)
+    g = torch.Generator().manual_seed(99)
+    host = [torch.randint(0, 256, (batch, 3, args.height, args.width), generator=g, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    target = torch.randint(0, args.classes, (batch, 1, args.height, args.width), device=dev)
+    bufs = [torch.empty_like(h, device=dev) for h in host]
+    ev = iouEval(args.classes)
+    with torch.no_grad():
+        model.evaluate_batch(bufs[0], target, ev, torch.uint8, ways=args.infer_ways)
+    torch.cuda.synchronize()
+    graphs = []
+    for b in bufs:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"), torch.no_grad():
+            model.evaluate_batch(b, target, ev, torch.uint8, ways=args.infer_ways)
+        graphs.append(gr)
+    copy_stream = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    copied = [torch.cuda.Event() for _ in bufs]
+    consumed = [torch.cuda.Event() for _ in bufs]
+    for e in consumed:
+        e.record(main)
+
+    def step(i):
+        k = i & 1
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[k])          # the batch that last used this buffer has been computed
+            bufs[k].copy_(host[k], non_blocking=True)
+            copied[k].record(copy_stream)
+        if i > 0:                                        # compute the batch copied one step earlier
+            j = (i - 1) & 1
+            main.wait_event(copied[j])
+            graphs[j].replay()
+            consumed[j].record(main)
+
+    for i in range(warmup + 1):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup + 1, warmup + 1 + steps):
+        step(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    nbytes = host[0].numel()
+    return {"value": batch * steps / elapsed, "unit": "img/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
+            "dtype": args.dtype, "h2d_bytes_per_step": nbytes, "h2d_gbs": nbytes * steps / elapsed / 1e9,
+            "config": {"workload": f"as the headline, each batch copied from pinned host memory as uint8 [N,3,{args.height},{args.width}] "
+                                   "on a copy stream, double-buffered; / 255 applied by the initial block on load",
+                       "hip_graph": True, "streams": max(1, min(args.infer_ways, batch))}}
+
+
 def run_multi(args, world, rank, dev):
     """Multi-task variant (train/multi_models.py): shared encoder, two regression decoders with skips, classifier."""
     from erfnet_pytorch_amd import multi_models as MM, synthetic as S
@@ -478,6 +537,8 @@ def main():
             one.infer_ways = 1
             res["inference_one_chain"] = leg(run_infer(one, world, rank, dev, steps=15, warmup=3, roofline=False))
             free_gpu()
+        res["inference_with_h2d"] = run_infer_h2d(args, dev, steps=20, warmup=4)
+        free_gpu()
         if not args.no_train:
             res["training"] = leg(run_train(args, world, rank, dev, steps=args.train_steps, warmup=args.train_warmup, batch=args.train_batch))
             free_gpu()

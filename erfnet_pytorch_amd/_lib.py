@@ -145,7 +145,7 @@ SIGNATURES = {
     "erf_pointwise_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
     "erf_pointwise_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, c_size_t, P]),
     "erf_probe_mfma_flop": (LL, [I, I, I]),
-    "erf_probe_mfma": (I, [I, I, I, P, P, P]),
+    "erf_probe_mfma": (I, [I, I, I, P, P]),
     "erf_probe_copy": (I, [P, P, LL, I, P]),
     "erf_static_scratch_max_channels": (I, []),
     "erf_bn_stats_finalize_static": (I, [P, I, LL, I, P, P, P, P, F, F, P, P, P, P, P]),

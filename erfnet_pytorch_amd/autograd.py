@@ -505,7 +505,12 @@ class _NB1dFn(torch.autograd.Function):
 class _DownFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, w, b, gamma, beta):
-        code = ops.dt(x) if mod.ninput != 3 else getattr(mod, "_erf_code", ops.dt(x))
+        if mod.ninput != 3:
+            code = ops.dt(x)
+        else:
+            code = mod.__dict__.get("_erf_code")
+            if code is None:
+                code = ops.image_code(x)
         cin, cout = mod.ninput, mod.noutput
         cc = cout - cin
         shift = torch.zeros(cout, device=x.device)
@@ -550,7 +555,7 @@ class _DownFn(torch.autograd.Function):
         if cin == 3:
             cpad = 8 if code == BF16 else 4
             xpad = torch.empty((n, 2 * ho, 2 * wo, cpad), dtype=z.dtype, device=dev)
-            call("erf_image_to_nhwc_padded", xh.data_ptr(), ops.dt(xh), xpad.data_ptr(), code, n, 2 * ho, 2 * wo, _stream())
+            call("erf_image_to_nhwc_padded", xh.data_ptr(), ops.image_source(xh)[0], xpad.data_ptr(), code, n, 2 * ho, 2 * wo, _stream())
             nb = size_query("erf_wgrad_workspace_bytes", 13, cpad, 9, n * ho * wo)
             ws = _ws(nb, dev)
             wgrad_deferred(dev, (ws, dw, xpad), "erf_stem_wgrad", xpad.data_ptr(), dz.data_ptr(), dw.data_ptr(), code, n, 2 * ho,
@@ -753,7 +758,7 @@ def block_forward(mod, x):
 
 def _compute_code(owner, x):
     cd = getattr(owner, "compute_dtype", None)
-    return ops.dt(x) if cd is None else (BF16 if cd == torch.bfloat16 else F32)
+    return ops.image_code(x) if cd is None else (BF16 if cd == torch.bfloat16 else F32)
 
 
 def encoder_forward(enc, x, predict=False, code=None):
@@ -762,7 +767,7 @@ def encoder_forward(enc, x, predict=False, code=None):
     for layer in enc.layers:
         y = block_forward(layer, y)
     if predict:
-        y = _PointwiseFn.apply(y, enc.output_conv.weight, enc.output_conv.bias, x.dtype == torch.float32, enc.output_conv)
+        y = _PointwiseFn.apply(y, enc.output_conv.weight, enc.output_conv.bias, ops.image_is_f32(x), enc.output_conv)
     return y
 
 
@@ -883,4 +888,4 @@ def erfnet_backward_sections(y, sums, state):
 
 def erfnet_forward(net, x):
     feats = encoder_forward(net.encoder, x, code=_compute_code(net, x))
-    return decoder_forward(net.decoder, feats, logits_f32=x.dtype == torch.float32)
+    return decoder_forward(net.decoder, feats, logits_f32=ops.image_is_f32(x))

@@ -117,7 +117,7 @@ int erf_downsampler(const void* x, void* y, const void* packed, const float* sca
 
 int erf_stem_downsampler(const void* x_nchw, int x_dtype, void* y, const float* w, const float* scale, const float* shift,
                          int dtype, int N, int Hin, int Win, int relu, void* stream) {
-    if (!x_nchw || !y || !w || !dtype_ok(dtype) || !dtype_ok(x_dtype) || N <= 0 || Hin <= 0 || Win <= 0) return ERF_EINVAL;
+    if (!x_nchw || !y || !w || !dtype_ok(dtype) || x_dtype < 0 || x_dtype > ERF_U8_NHWC || N <= 0 || Hin <= 0 || Win <= 0) return ERF_EINVAL;
     return stem_launch(x_nchw, x_dtype, y, w, scale, shift, dtype, N, Hin, Win, relu, (hipStream_t)stream);
 }
 

@@ -542,7 +542,7 @@ int erf_downsampler_wgrad(const void* x, const void* dz, float* dw, int dtype, i
 // Stem (3 -> 16): x_pad is the image as NHWC with the channels zero-padded to `cpad` (8 for bf16, 4 for
 // fp32; erf_image_to_nhwc_padded), dz the [N,Hin/2,Win/2,16] gradient of the block's pre-BN output.
 int erf_image_to_nhwc_padded(const void* x_nchw, int x_dtype, void* out, int dtype, int N, int H, int W, void* stream) {
-    if (!x_nchw || !out || !dtype_ok(dtype) || !dtype_ok(x_dtype) || N <= 0) return ERF_EINVAL;
+    if (!x_nchw || !out || !dtype_ok(dtype) || x_dtype < 0 || x_dtype > ERF_U8_NHWC || N <= 0) return ERF_EINVAL;
     return image_pad_launch(x_nchw, x_dtype, out, dtype, N, (long long)H * W, dtype == ERF_BF16 ? 8 : 4, (hipStream_t)stream);
 }
 

@@ -8,11 +8,19 @@
 // 13 conv3x3-s2 channels (27 inputs each) and 3 max-pool channels, affine + ReLU, one
 // 32-byte (bf16) / 64-byte (fp32) store.  The 351 weights sit in LDS and are read as
 // wave-wide broadcasts.
-template <typename TIN, typename T>
+// uint8 images (TIN = uint8_t; LAY 0: planar [N,3,H,W], 1: interleaved [N,H,W,3], the layout image decoders deliver) are
+// converted on load the way the reference's input transform does it (ToTensor(), train/main.py:47,66 / eval/eval_iou.py:31:
+// value / 255 as a correctly rounded fp32 division): the 256 possible quotients are formed once per workgroup in LDS.
+template <typename TIN, typename T, int LAY = 0>
 __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T* __restrict__ y,
                                                    const float* __restrict__ w, const float* __restrict__ scale,
                                                    const float* __restrict__ shift, int N, int Hin, int Win, int relu,
                                                    float* __restrict__ raw_out) {
+    __shared__ float lut[sizeof(TIN) == 1 ? 256 : 1];
+    if constexpr (sizeof(TIN) == 1) {
+        lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+        __syncthreads();
+    }
     // The 351 weights and 32 affine coefficients are read at wave-uniform, compile-time offsets, i.e. through the
     // scalar cache into SGPRs: every FMA takes its weight as a scalar operand (no LDS traffic, no VGPRs).
     const int Ho = Hin >> 1, Wo = Win >> 1;
@@ -43,6 +51,20 @@ __global__ __launch_bounds__(256) void stem_kernel(const TIN* __restrict__ x, T*
                 in[c * 9 + th * 3 + 1] = rowok ? rgt[0] : 0.f;
                 in[c * 9 + th * 3 + 2] = rowok ? rgt[1] : 0.f;
             }
+    } else if constexpr (sizeof(TIN) == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int th = 0; th < 3; ++th)
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) {
+                    const int hi = 2 * ho - 1 + th, wi = 2 * wo - 1 + tw;
+                    const bool ok = hi >= 0 && hi < Hin && wi >= 0 && wi < Win;
+                    const long long at = LAY ? ((long long)(ok ? hi : 0) * Win + (ok ? wi : 0)) * 3 + c
+                                             : c * plane + (long long)(ok ? hi : 0) * Win + (ok ? wi : 0);
+                    const float v = lut[xb[at]];
+                    in[c * 9 + th * 3 + tw] = ok ? v : 0.f;
+                }
     } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -102,6 +124,12 @@ int stem_launch(const void* x, int x_dtype, void* y, const float* w, const float
     else if (x_dtype == 0 && dtype == 1) STEM(float, bf16raw);
     else if (x_dtype == 1 && dtype == 1) STEM(bf16raw, bf16raw);
     else if (x_dtype == 1 && dtype == 0) STEM(bf16raw, float);
+#define STEM8(T, LAY) hipLaunchKernelGGL((stem_kernel<uint8_t, T, LAY>), dim3(grid), dim3(256), 0, stream, (const uint8_t*)x, (T*)y, w, scale, shift, N, Hin, Win, relu, (float*)nullptr)
+    else if (x_dtype == 2 && dtype == 0) STEM8(float, 0);
+    else if (x_dtype == 2 && dtype == 1) STEM8(bf16raw, 0);
+    else if (x_dtype == 3 && dtype == 0) STEM8(float, 1);
+    else if (x_dtype == 3 && dtype == 1) STEM8(bf16raw, 1);
+#undef STEM8
     else return ERF_EUNSUPPORTED;
 #undef STEM
     return erf_check_launch();

@@ -971,14 +971,21 @@ int patches_launch(const void* dl, int src_dtype, void* out, int dtype, int N, i
 }
 
 // image NCHW [N,3,H,W] -> NHWC [N,H,W,cpad] (channels >= 3 zero), operand of the stem's weight gradient
-template <typename TS, typename T>
+// uint8 sources (LAY 0: planar, 1: interleaved [N,H,W,3]) become value / 255 (correctly rounded fp32 division), as in stem_kernel
+template <typename TS, typename T, int LAY = 0>
 __global__ __launch_bounds__(256) void image_pad_kernel(const TS* __restrict__ x, T* __restrict__ out, long long N, long long HW,
                                                         int cpad) {
     const long long total = N * HW;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long n = idx / HW, hw = idx % HW;
-        for (int c = 0; c < cpad; ++c)
-            Elem<T>::st(out + idx * cpad + c, c < 3 ? Elem<TS>::ld(x + (n * 3 + c) * HW + hw) : 0.f);
+        for (int c = 0; c < cpad; ++c) {
+            float v = 0.f;
+            if (c < 3) {
+                if constexpr (sizeof(TS) == 1) v = (float)x[LAY ? idx * 3 + c : (n * 3 + c) * HW + hw] / 255.0f;
+                else v = Elem<TS>::ld(x + (n * 3 + c) * HW + hw);
+            }
+            Elem<T>::st(out + idx * cpad + c, v);
+        }
     }
 }
 
@@ -989,6 +996,12 @@ int image_pad_launch(const void* x, int src_dtype, void* out, int dtype, int N, 
     else if (src_dtype == 0 && dtype == 1) IP(float, bf16raw);
     else if (src_dtype == 1 && dtype == 1) IP(bf16raw, bf16raw);
     else if (src_dtype == 1 && dtype == 0) IP(bf16raw, float);
+#define IP8(T, LAY) hipLaunchKernelGGL((image_pad_kernel<uint8_t, T, LAY>), dim3(ew_grid(total)), dim3(256), 0, stream, (const uint8_t*)x, (T*)out, (long long)N, HW, cpad)
+    else if (src_dtype == 2 && dtype == 0) IP8(float, 0);
+    else if (src_dtype == 2 && dtype == 1) IP8(bf16raw, 0);
+    else if (src_dtype == 3 && dtype == 0) IP8(float, 1);
+    else if (src_dtype == 3 && dtype == 1) IP8(bf16raw, 1);
+#undef IP8
     else return ERF_EUNSUPPORTED;
 #undef IP
     return erf_check_launch();

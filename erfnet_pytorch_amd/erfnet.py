@@ -98,10 +98,11 @@ class DownsamplerBlock(_Block):
         if self.training or _needs_autograd(self, input):
             from . import autograd as ag
             return ag.block_forward(self, input)
-        return ops.to_nchw_view(self.forward_image(input, ops.dt(input)))
+        return ops.to_nchw_view(self.forward_image(input, ops.image_code(input)))
 
     def forward_image(self, image_nchw, code):
-        """3 -> 16 initial block: reads the NCHW image directly."""
+        """3 -> 16 initial block: reads the NCHW image directly (fp32 / bf16, or 8-bit images [N,3,H,W] / [N,H,W,3], which
+        it turns into value / 255 on load: ToTensor() of train/main.py:47,66)."""
         c = self._cached(code)
         return ops.stem(image_nchw.contiguous(), c["w"], c["s"], c["t"], code)
 
@@ -205,11 +206,11 @@ class Encoder(nn.Module):
         if self.training or _needs_autograd(self, input):
             from . import autograd as ag
             return ag.encoder_forward(self, input, predict)
-        code = ops.dt(input) if self.compute_dtype is None else (BF16 if self.compute_dtype == torch.bfloat16 else F32)
+        code = ops.image_code(input) if self.compute_dtype is None else (BF16 if self.compute_dtype == torch.bfloat16 else F32)
         x = self.forward_features_nhwc(input, code)
         if predict:
             w, b = self._head(code)
-            return ops.pointwise(x, w, b, self.output_conv.out_channels, out_f32=input.dtype == torch.float32)
+            return ops.pointwise(x, w, b, self.output_conv.out_channels, out_f32=ops.image_is_f32(input))
         return ops.to_nchw_view(x)
 
 
@@ -261,7 +262,7 @@ class ERFNet(nn.Module):
 
     def _code(self, input):
         cd = self.compute_dtype
-        return ops.dt(input) if cd is None else (BF16 if cd == torch.bfloat16 else F32)
+        return ops.image_code(input) if cd is None else (BF16 if cd == torch.bfloat16 else F32)
 
     def forward(self, input, only_encode=False):
         ops.require_gpu(input, "ERFNet")
@@ -273,7 +274,7 @@ class ERFNet(nn.Module):
             from . import autograd as ag
             return ag.erfnet_forward(self, input)
         x = self.encoder.forward_features_nhwc(input, self._code(input))
-        logits, _ = self.decoder.forward_nhwc(x, logits_f32=input.dtype == torch.float32)
+        logits, _ = self.decoder.forward_nhwc(x, logits_f32=ops.image_is_f32(input))
         return logits
 
     @torch.no_grad()
@@ -313,7 +314,7 @@ class ERFNet(nn.Module):
             if isinstance(m, _Block):
                 m._cached(code)
         self.decoder._head(code)
-        n, _, h, w = input.shape
+        _, n, h, w = ops.image_source(input)
         labels = torch.empty((n, h, w), dtype=label_dtype, device=input.device)
         cur = torch.cuda.current_stream(input.device)
         side = _SIDE_STREAMS.setdefault(input.device.index, [])      # per device, not on the module: a module must stay copyable

@@ -31,6 +31,35 @@ def dt(t: torch.Tensor) -> int:
     raise TypeError(f"erfnet_pytorch_amd computes in float32 or bfloat16, got {t.dtype}")
 
 
+# 8-bit images as decoders deliver them (the reference's loaders hand PIL images to ToTensor(), train/main.py:47,66): the
+# initial block converts them on load to value / 255 in fp32, so a uint8 batch gives the bits of `images.float() / 255`.
+U8_NCHW, U8_NHWC = 2, 3
+
+
+def image_source(t: torch.Tensor):
+    """(source code for the initial block, N, H, W) of a network input: fp32 / bf16 [N,3,H,W], uint8 [N,3,H,W] or uint8 [N,H,W,3]."""
+    if t.dim() != 4:
+        raise ValueError(f"expected a batch of images [N,3,H,W] (or uint8 [N,H,W,3]), got shape {tuple(t.shape)}")
+    if t.dtype == torch.uint8:
+        if t.shape[1] == 3:
+            return U8_NCHW, t.shape[0], t.shape[2], t.shape[3]
+        if t.shape[3] == 3:
+            return U8_NHWC, t.shape[0], t.shape[1], t.shape[2]
+        raise ValueError(f"uint8 images are [N,3,H,W] or [N,H,W,3], got shape {tuple(t.shape)}")
+    if t.shape[1] != 3:
+        raise ValueError("the initial block takes 3-channel images")
+    return dt(t), t.shape[0], t.shape[2], t.shape[3]
+
+
+def image_code(t: torch.Tensor) -> int:
+    """Compute dtype code an image batch implies when the model sets none: uint8 images are fp32 after ToTensor()."""
+    return F32 if t.dtype == torch.uint8 else dt(t)
+
+
+def image_is_f32(t: torch.Tensor) -> bool:
+    return t.dtype in (torch.float32, torch.uint8)
+
+
 def tdtype(code: int) -> torch.dtype:
     return torch.bfloat16 if code == BF16 else torch.float32
 
@@ -293,13 +322,11 @@ def downsampler(x, packed, scale, shift, cout: int, relu: bool = True, out=None)
 
 
 def stem(x_nchw, w, scale, shift, code: int, relu: bool = True, out=None):
-    n, c, h, w_ = x_nchw.shape
-    if c != 3:
-        raise ValueError("the initial block takes 3-channel images")
+    src, n, h, w_ = image_source(x_nchw)
     if out is None:
         return T.stem(x_nchw, w, scale, shift, code, relu)
     y = out
-    call("erf_stem_downsampler", x_nchw.data_ptr(), dt(x_nchw), y.data_ptr(), w.data_ptr(), _p(scale), _p(shift), code,
+    call("erf_stem_downsampler", x_nchw.data_ptr(), src, y.data_ptr(), w.data_ptr(), _p(scale), _p(shift), code,
          n, h, w_, int(relu), _stream())
     return y
 

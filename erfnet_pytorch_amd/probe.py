@@ -27,20 +27,22 @@ def _time_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+SIMDS_PER_CU = 4
+BF16_FLOP_PER_SIMD_CYCLE = 1024          # v_mfma_f32_16x16x32_bf16: 16384 flop in 16 cycles
+F32_FLOP_PER_SIMD_CYCLE = 64             # v_mfma_f32_16x16x4_f32: 2048 flop in 32 cycles
+
+
 def mfma_peak(dtype_code: int, dev, workgroups: int = 0, iters: int = 20000, reps: int = 3):
-    """(sustained TFLOP/s, shader clock in GHz the loop ran at).  Default: four workgroups of 8 waves per CU, which the
-    kernel's registers and the 8 wave slots of a SIMD hold all at once, so every wave's loop spans the whole launch (a few
-    milliseconds) and the clock is the cycles one wave counted divided by the launch time."""
+    """(sustained TFLOP/s, the shader clock in GHz that rate implies at the instruction's issue cost).  Default: sixteen
+    workgroups of 8 waves per CU; a launch lasts a few milliseconds."""
     cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    workgroups = workgroups or 4 * cu
+    workgroups = workgroups or 16 * cu
     sink = torch.zeros(1, device=dev)
-    cycles = torch.zeros(1, dtype=torch.int64, device=dev)
     flop = query("erf_probe_mfma_flop", dtype_code, workgroups, iters)
-    ms = _time_ms(lambda: call("erf_probe_mfma", dtype_code, workgroups, iters, sink.data_ptr(), cycles.data_ptr(), _stream()), reps)
-    loop_cycles = int(cycles.item())
-    rounds = max(1.0, workgroups / (4.0 * cu))                    # more than four per CU run in rounds
-    ghz = loop_cycles / (ms * 1e-3 / rounds) / 1e9
-    return flop / (ms * 1e-3) / 1e12, ghz
+    ms = _time_ms(lambda: call("erf_probe_mfma", dtype_code, workgroups, iters, sink.data_ptr(), _stream()), reps)
+    rate = flop / (ms * 1e-3)
+    per_cycle = cu * SIMDS_PER_CU * (BF16_FLOP_PER_SIMD_CYCLE if dtype_code == 1 else F32_FLOP_PER_SIMD_CYCLE)
+    return rate / 1e12, rate / per_cycle / 1e9
 
 
 def copy_peak(dev, nbytes: int = 1 << 30, reps: int = 5):
@@ -50,7 +52,7 @@ def copy_peak(dev, nbytes: int = 1 << 30, reps: int = 5):
     dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     src.fill_(1)
     best = 0.0
-    for wgs in (2048, 4096, 8192, 16384):
+    for wgs in (1024, 2048, 4096, 8192, 16384):
         ms = _time_ms(lambda: call("erf_probe_copy", src.data_ptr(), dst.data_ptr(), nbytes, wgs, _stream()), reps)
         best = max(best, 2.0 * nbytes / (ms * 1e-3) / 1e9)
     return best
@@ -59,6 +61,6 @@ def copy_peak(dev, nbytes: int = 1 << 30, reps: int = 5):
 def measured_peaks(dev):
     bf16, ghz_b = mfma_peak(1, dev)
     f32, ghz_f = mfma_peak(0, dev, iters=10000)
-    return {"mfma_bf16_tflops": bf16, "mfma_bf16_clock_ghz": ghz_b, "mfma_f32_tflops": f32, "mfma_f32_clock_ghz": ghz_f,
+    return {"mfma_bf16_tflops": bf16, "mfma_bf16_implied_clock_ghz": ghz_b, "mfma_f32_tflops": f32, "mfma_f32_implied_clock_ghz": ghz_f,
             "hbm_copy_gbs": copy_peak(dev),
             "how": "erf_probe_mfma: MFMA-only loop, 8 chains x 2 waves per SIMD on every CU; erf_probe_copy: 1 GiB, 16 B per lane, read + write bytes"}

@@ -169,19 +169,33 @@ _register("downsampler(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, in
           lambda x, packed, scale, shift, cout, relu: x.new_empty((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, cout)))
 
 
+def _stem_geometry(x):
+    """(source code, N, H, W): fp32 / bf16 / uint8 [N,3,H,W] or uint8 [N,H,W,3] (interleaved, as image decoders deliver)."""
+    if x.dim() != 4:
+        raise ValueError("the initial block takes a batch of 3-channel images")
+    if x.dtype == torch.uint8 and x.shape[1] != 3 and x.shape[3] == 3:
+        return 3, x.shape[0], x.shape[1], x.shape[2]
+    if x.shape[1] != 3:
+        raise ValueError("the initial block takes 3-channel images: [N,3,H,W], or uint8 [N,H,W,3]")
+    return (2 if x.dtype == torch.uint8 else _dt(x)), x.shape[0], x.shape[2], x.shape[3]
+
+
 def _stem(x_nchw, w, scale, shift, code, relu):
-    n, c, h, w_ = x_nchw.shape
-    if c != 3 or not x_nchw.is_contiguous():
-        raise ValueError("the initial block takes contiguous 3-channel NCHW images")
+    src, n, h, w_ = _stem_geometry(x_nchw)
+    if not x_nchw.is_contiguous():
+        raise ValueError("the initial block takes contiguous images")
     y = torch.empty((n, h // 2, w_ // 2, 16), dtype=torch.bfloat16 if code == BF16 else torch.float32, device=x_nchw.device)
-    call("erf_stem_downsampler", x_nchw.data_ptr(), _dt(x_nchw), y.data_ptr(), w.data_ptr(), _p(scale), _p(shift), code,
+    call("erf_stem_downsampler", x_nchw.data_ptr(), src, y.data_ptr(), w.data_ptr(), _p(scale), _p(shift), code,
          n, h, w_, int(relu), _stream())
     return y
 
 
-_register("stem(Tensor x_nchw, Tensor w, Tensor? scale, Tensor? shift, int code, bool relu) -> Tensor", _stem,
-          lambda x, w, scale, shift, code, relu: x.new_empty((x.shape[0], x.shape[2] // 2, x.shape[3] // 2, 16),
-                                                             dtype=torch.bfloat16 if code == BF16 else torch.float32))
+def _stem_fake(x, w, scale, shift, code, relu):
+    _, n, h, w_ = _stem_geometry(x)
+    return x.new_empty((n, h // 2, w_ // 2, 16), dtype=torch.bfloat16 if code == BF16 else torch.float32)
+
+
+_register("stem(Tensor x_nchw, Tensor w, Tensor? scale, Tensor? shift, int code, bool relu) -> Tensor", _stem, _stem_fake)
 
 
 def _upsampler(x, packed, scale, shift, cout, relu):

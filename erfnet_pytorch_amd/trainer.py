@@ -70,7 +70,7 @@ def _refresh_bank(bank, model, images):
     """(Re)build the model's PackedBank for the step's compute dtype and re-pack every factorized-conv weight."""
     from . import ops
     cd = getattr(model, "compute_dtype", None)
-    code = ops.dt(images) if cd is None else (ops.BF16 if cd == torch.bfloat16 else ops.F32)
+    code = ops.image_code(images) if cd is None else (ops.BF16 if cd == torch.bfloat16 else ops.F32)
     if bank is None or bank.code != code:
         bank = ops.PackedBank(model, code)
     bank.refresh()

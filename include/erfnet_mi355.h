@@ -32,6 +32,11 @@ extern "C" {
 
 #define ERF_F32 0
 #define ERF_BF16 1
+/* image sources only (x_dtype of erf_stem_downsampler / erf_image_to_nhwc_padded): 8-bit images as decoders deliver them,
+ * converted on load to value / 255 in fp32, i.e. ToTensor() of the reference's input transform (train/main.py:47,66;
+ * eval/eval_iou.py:31).  ERF_U8_NCHW: planar [N,3,H,W]; ERF_U8_NHWC: interleaved [N,H,W,3]. */
+#define ERF_U8_NCHW 2
+#define ERF_U8_NHWC 3
 
 #define ERF_AXIS_H 0 /* 3x1 kernel: taps along rows    */
 #define ERF_AXIS_W 1 /* 1x3 kernel: taps along columns */
@@ -93,7 +98,8 @@ int erf_downsampler_pack(const float* w, void* packed, int dtype, int Cin, int C
 int erf_downsampler(const void* x, void* y, const void* packed, const float* scale, const float* shift, int dtype,
                     int N, int Hin, int Win, int Cin, int Cout, int relu, void* stream);
 /* The 3 -> 16 initial_block (train/erfnet.py:80): x is the NCHW network input
- * [N,3,Hin,Win] of type x_dtype; w fp32 [13][3][3][3] unpacked; y NHWC [N,Hin/2,Win/2,16]. */
+ * [N,3,Hin,Win] of type x_dtype (ERF_F32 / ERF_BF16, or one of the two uint8 image sources above, for which the kernel
+ * applies ToTensor()'s / 255 on load); w fp32 [13][3][3][3] unpacked; y NHWC [N,Hin/2,Win/2,16]. */
 int erf_stem_downsampler(const void* x_nchw, int x_dtype, void* y, const float* w, const float* scale,
                          const float* shift, int dtype, int N, int Hin, int Win, int relu, void* stream);
 
@@ -413,10 +419,9 @@ int erf_linear_bwd(const float* f, const float* w, const float* dy, float* df, f
 /* ---- peak probes (no counterpart in the reference, which times whole forward passes only: eval/eval_forwardTime.py:40-59) ----
  * What this part sustains on the two resources the roofline fractions are priced against.  erf_probe_mfma: a
  * matrix-instruction-only loop (dtype 1: v_mfma_f32_16x16x32_bf16, 0: v_mfma_f32_16x16x4_f32; `workgroups` of 8 waves, `iters`
- * trips of 8 independent chains per wave); erf_probe_mfma_flop: the flop such a launch executes; cycles[0] receives the
- * shader-clock cycles of one wave's loop.  erf_probe_copy: streaming copy of `bytes` (multiple of 16) by `workgroups` x 256 lanes. */
+ * trips of 8 independent chains per wave); erf_probe_mfma_flop: the flop such a launch executes.  erf_probe_copy: streaming copy of `bytes` (multiple of 16) by `workgroups` x 256 lanes. */
 long long erf_probe_mfma_flop(int dtype, int workgroups, int iters);
-int erf_probe_mfma(int dtype, int workgroups, int iters, float* sink, long long* cycles, void* stream);
+int erf_probe_mfma(int dtype, int workgroups, int iters, float* sink, void* stream);
 int erf_probe_copy(const void* src, void* dst, long long bytes, int workgroups, void* stream);
 
 /* ---- the one entry point that allocates nothing and takes no workspace ------------------------------------------

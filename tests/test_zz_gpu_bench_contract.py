@@ -45,6 +45,8 @@ def test_single_gpu_line_has_every_leg():
     assert mp["mfma_bf16_tflops"] > 100 and mp["mfma_f32_tflops"] > 10 and mp["hbm_copy_gbs"] > 500
     assert abs(rf["frac_of_measured"] - rf["achieved"] / mp["hbm_copy_gbs"]) < 1e-9 and "frac_of_measured" in rb
     assert abs(d["mfma_frac"] - d["model_tflops"] / 2500.0) < 1e-9 and d["mfma_frac_of_measured"] > d["mfma_frac"]
+    h2d = d["inference_with_h2d"]
+    assert h2d["value"] > 0 and h2d["h2d_bytes_per_step"] == 2 * 3 * 64 * 128 and "uint8" in h2d["config"]["workload"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     tr = d["training"]
