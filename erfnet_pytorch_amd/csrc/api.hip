@@ -75,7 +75,7 @@ int erf_nb1d_block_infer(const void* x, void* y, const void* packed1, const void
         return ERF_EINVAL;
     const void* const packed[4] = {packed1, packed2, packed3, packed4};
     if (C == 16) return nb1d_block16_launch(x, y, packed, table, dtype, N, H, W, C, dilation, (hipStream_t)stream);
-    return nb1d_block_launch(x, y, packed, table, dtype, N, H, W, C, dilation, (hipStream_t)stream);
+    return nb1d_block64s_launch(x, y, packed, table, dtype, N, H, W, C, dilation, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ DownsamplerBlock

@@ -30,11 +30,12 @@ int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* s
                       int relu, hipStream_t stream, const Conv1dBnTail* tail = nullptr);
 int conv1d_buf_max_groups();
 
-// A whole non_bottleneck_1d block (four factorized convolutions, folded BatchNorms, residual) in one launch: bf16, C = 64,
-// dilation 1 (nb1d_block.hip).  packed4: the four mode-0 packed weights; tab: [4][scale | shift][C] fp32 in device memory.
-// ERF_EUNSUPPORTED for every other shape (nothing launched).
-int nb1d_block_launch(const void* x, void* y, const void* const* packed4, const float* tab, int dtype, int N, int H, int W, int C,
-                      int dilation, hipStream_t stream);
-// The same block for C = 16 (nb1d_block16.hip): same arguments, same status codes.
+// A whole non_bottleneck_1d block (four factorized convolutions, folded BatchNorms, residual) in one launch, bf16, dilation 1.
+// packed4: the four mode-0 packed weights; tab: [4][scale | shift][C] fp32 in device memory.  ERF_EUNSUPPORTED for every other
+// shape (nothing launched).
+// C = 16: one workgroup per tile, three workgroups per CU (nb1d_block16.hip).
 int nb1d_block16_launch(const void* x, void* y, const void* const* packed4, const float* tab, int dtype, int N, int H, int W, int C,
                         int dilation, hipStream_t stream);
+// C = 64: a stream of rows through four wave roles (nb1d_block64s.hip).
+int nb1d_block64s_launch(const void* x, void* y, const void* const* packed4, const float* tab, int dtype, int N, int H, int W, int C,
+                         int dilation, hipStream_t stream);

@@ -1,0 +1,439 @@
+// A whole non_bottleneck_1d block in one launch for 64 channels, as a STREAM of image rows through four wave roles
+// (bf16 inference, dilation 1; train/erfnet.py:58-74 with both BatchNorms in eval mode folded into scale / shift):
+//
+//   a1 = relu(conv3x1(x) + t1);  a2 = relu(s2 * conv1x3(a1) + t2);  a3 = relu(conv3x1(a2) + t3);
+//   y  = relu(s4 * conv1x3(a3) + t4 + x)
+//
+// Run as two conv1d_pair launches the block moves five maps through HBM (x, a2 | a2, x again, y) and its waves walk two
+// matrix phases and four barriers per tile in lockstep.  Here x is read once and y written once, a1 / a2 / a3 live in LDS
+// only, and the eight waves of the one workgroup a CU holds are split by ROLE instead of by output channel:
+//
+//   waves 0,1: conv3x1_1   waves 2,3: conv1x3_1   waves 4,5: conv1x3_2   waves 6,7: conv3x1_2
+//   (waves w and w + 4 share a SIMD: the pairing puts the role with the most vector work beside the one with the least)
+//
+// each wave keeping ALL 64 output channels of its convolution in registers (96 registers of weights) for two of the four
+// 16-pixel matrix tiles of a row, so every 1 KB pixel-fragment read feeds four matrix instructions.
+//
+// The unit of work is one row of a column STRIP: a frame of 64 columns (local column c = image column - c0 + 2) of which
+// 60 are output columns (c in [2, 62)); the two columns either side are the halo the two 1x3 convolutions need and are
+// recomputed by the neighbouring strip.  A workgroup marches down its strip one row per step, all roles working at once on
+// different rows -- the vertical halo of the two 3x1 convolutions costs nothing, their three taps are simply the three
+// youngest rows of a ring buffer:
+//
+//   step t:  DMA       x row t  requested -> X[t % 8]; it is first read D = 2 steps after the step of its request
+//            conv3x1_1 a1 row u = t-2-D  from X[u-1], X[u], X[u+1]       -> A1[u % 2]
+//            conv1x3_1 a2 row u = t-3-D  from A1[u % 2]                   -> A2[u % 4]   (zeros for rows outside the image)
+//            conv3x1_2 a3 row u = t-5-D  from A2[u-1], A2[u], A2[u+1]     -> A3[u % 2]
+//            conv1x3_2 y' row u = t-6-D  from A3[u % 2]                   -> Y[u % 2]    (bf16(s4 * acc + t4), staged)
+//            finish    y  row u = t-7-D  = relu(Y[u % 2] + x row u)       -> HBM as whole 16-byte chunks; x is re-read from
+//                                            global memory (an L2 hit: this CU fetched the row nine steps ago), requested one
+//                                            step ahead
+//   one workgroup barrier per step.  The x requests are issued by the four 3x1 waves (2 KB each), the rows are finished by
+//   the four 1x3 waves (16 pixels each): a wave's memory operations complete in order, so a wave that waits for an L2 hit
+//   must not have HBM requests queued in front of it.
+//
+// Every row of every ring has the same layout: 66 pixel slots of 128 bytes (slot = local column + 1; slots 0 and 65 stay
+// zero and only ever feed the frame's outermost columns, which no output column depends on), the eight 16-byte chunks of a
+// pixel XOR-swizzled by the slot index so that a fragment read (16 consecutive pixels, one chunk per quarter wave) is free
+// of bank conflicts.  18 rows = 152 KB of LDS.
+//
+// A workgroup's rows are a contiguous run of the linearised (image, strip, row) space, cut where it crosses into the next
+// strip; each piece ("chunk") of RC output rows takes RC + 4 steps (rows r0-2 .. r0+RC+1 are loaded, a1 / a2 are formed
+// on RC + 2 of them), and the roles simply keep stepping from one chunk into the next, so the pipeline fills and drains
+// once per workgroup, not once per chunk.  Intermediate values outside the image are forced to zero where the next
+// convolution pads with zeros: a1 and a3 in columns outside the image, a2 in rows outside the image; x outside the image
+// reads as zero through the buffer descriptor.
+//
+// Sums: every accumulator receives its six K-steps in the order of conv1d_pair_kernel (taps ascending, channel chunks
+// ascending), with the same matrix instruction, and the epilogues round where that kernel's do -- the output is
+// bit-identical to the two-launch path.
+#include "common.cuh"
+#include "conv1d.cuh"
+#include "conv1d_tile.cuh"
+
+typedef bf16raw T;
+
+namespace nbs {
+constexpr int C = 64, PIXB = 128, KS = 6, CT = 4;
+constexpr int FW = 64, TW = 60;                     // frame / output columns of a strip
+constexpr int ROWB = (FW + 2) * PIXB;               // 8448 bytes per ring row
+constexpr int NX = 8, NA1 = 2, NA2 = 4, NA3 = 2, NY = 2;
+constexpr int OFF_X = 0;
+constexpr int OFF_A1 = OFF_X + NX * ROWB;
+constexpr int OFF_A2 = OFF_A1 + NA1 * ROWB;
+constexpr int OFF_A3 = OFF_A2 + NA2 * ROWB;
+constexpr int OFF_Y = OFF_A3 + NA3 * ROWB;
+constexpr int OFF_TAB = OFF_Y + NY * ROWB;          // 152064: the slot table, 16 bytes per slot
+constexpr int MAX_SLOTS = 700;
+constexpr int LDS_BYTES = OFF_TAB + MAX_SLOTS * 16; // 163264
+constexpr int D = 2;                                // steps between the request of an x row and its first use
+constexpr int LAG1 = 2 + D, LAG2 = 3 + D, LAG3 = 5 + D, LAG4 = 6 + D, LAGY = 7 + D;
+static_assert(NX >= 4 + D && (NX & (NX - 1)) == 0, "an x row lives from its request to its last use as a conv3x1_1 tap");
+constexpr int PAD = 2 * PIXB;                       // the descriptors start two pixels before the tensors (column c0 - 2 of strip 0)
+constexpr int NTHREADS = 512;
+static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES % 16 == 0, "ring buffers fit the CU's LDS");
+}  // namespace nbs
+
+struct NbStreamParams {
+    const T* x;
+    T* y;
+    const void* w[4];
+    const float* tab;        // [4 convolutions][scale | shift][64] fp32
+    int N, H, W, S;          // S = strips per image
+    int rows_total;          // N * S * H
+    int rows_per_wg;
+    FastDiv fH, fS;
+    uint32_t bytes;          // N*H*W*128
+    int dbg;                 // -DERF_DEBUG builds only (ERF_BLOCK_DBG): 1 no matrix instructions, 2 no epilogue, 4 no row finishing,
+                             // 8 no x requests, 16 no fragment reads, 256 cycle stamps
+};
+
+#ifdef ERF_DEBUG
+// cycle stamps of a diagnostic build: [workgroup][wave][section], read back by erf_debug_block64s_stamps; nothing else reads them
+static __device__ unsigned long long g_nbs_stamps[256 * 8 * 8];
+#define NBS_DBG(bit) (p.dbg & (bit))
+#define NBS_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); st[i] += tn - tprev; tprev = tn; }
+#else
+#define NBS_DBG(bit) 0
+#define NBS_STAMP(i)
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace nbs {
+
+// What a role needs to know about the row ("slot") it works on in a step; wave-uniform.
+struct Slot {
+    int soff;    // byte offset of (image, row, column c0) from the tensor = of column c0 - 2 from the descriptor base
+    int c0;      // first output column of the strip
+    int fl;      // 1: slot exists, 2: a1 / a2 are formed on this row, 4: a3 / y are formed on this row, 8: row inside the image
+};
+
+template <int ROLE>
+__device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, const int wave, const int lane) {
+    constexpr bool VERT = ROLE == 0 || ROLE == 2;
+    constexpr int LAG = ROLE == 0 ? LAG1 : ROLE == 1 ? LAG2 : ROLE == 2 ? LAG3 : LAG4;
+    const int half = wave & 1;
+    const int q = lane >> 4, r16 = lane & 15;
+
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((const char*)p.x - PAD, p.bytes + PAD);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc((char*)p.y - PAD, p.bytes + PAD);
+
+    // ---- this role's weights (all 64 output channels) and epilogue constants
+    i32x4 w[CT][KS];
+    f32x4 sc[CT], sh[CT];
+    {
+        const i32x4* pw = (const i32x4*)p.w[ROLE];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[ct][ks] = pw[(ct * KS + ks) * 64 + lane];
+            sc[ct] = *(const f32x4*)(p.tab + (2 * ROLE) * C + ct * 16 + q * 4);
+            sh[ct] = *(const f32x4*)(p.tab + (2 * ROLE + 1) * C + ct * 16 + q * 4);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) tie_reg(w[ct][ks]);
+        asm volatile("" : "+v"(sc[ct]), "+v"(sh[ct]));
+    }
+
+    // ---- launch-invariant per-lane addressing (byte offsets inside a ring row)
+    const int p0 = 1 + 32 * half + r16;                  // slot of this lane's pixel in matrix tile 0 of this wave (tile 1: + 16 slots)
+    constexpr int NFO = VERT ? 2 : 6;
+    int fo[NFO];                                          // fragment reads: VERT [chunk half kc], else [tap][kc]
+    if constexpr (VERT) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) fo[kc] = p0 * PIXB + (((4 * kc + q) ^ (p0 & 7)) * 16);
+    } else {
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int pp = p0 + tap - 1;
+                fo[tap * 2 + kc] = pp * PIXB + (((4 * kc + q) ^ (pp & 7)) * 16);
+            }
+    }
+    int wo[CT];                                           // accumulator stores: channels 16 ct + 4 q .. + 3 of pixel p0
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wo[ct] = p0 * PIXB + (((ct * 2 + (q >> 1)) ^ (p0 & 7)) * 16) + (q & 1) * 8;
+    // this wave's share of a row's memory traffic (3x1 waves: the x request; 1x3 waves: finishing the output): local columns
+    // 16 duty .. 16 duty + 15, as two wave-wide accesses of 8 pixels, one 16-byte chunk per lane
+    const int duty = 2 * (ROLE >> 1) + half;
+    const int pc = 16 * duty + (lane >> 3);              // + 8 for the second access
+    const int kphys = lane & 7;                           // physical chunk position in the slot; it holds logical chunk klog
+    const int klog = kphys ^ ((pc + 1) & 7);              // (pc + 8 + 1) & 7 is the same
+    const uint32_t gvoff = (uint32_t)(pc * PIXB + klog * 16);     // global offset relative to (row, column c0 - 2); second: + 8 pixels
+    const int lfin = (pc + 1) * PIXB + kphys * 16;        // LDS offset of that chunk inside a ring row; second: + 8 slots
+#pragma unroll
+    for (int i = 0; i < NFO; ++i) asm volatile("" : "+v"(fo[i]));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(wo[ct]));
+
+    // ---- this workgroup's run of rows: nslots rows ("slots"), described by the table the prologue left in LDS
+    const int nslots = *(const int*)(smem + OFF_TAB + 12);            // entry 0 carries the count in its fourth word
+    const int nsteps = nslots + LAGY;
+    // slot e as three scalars; entries outside [0, nslots) are "nothing to do".  The 16-byte read is wave-uniform (a broadcast).
+    auto slot_load = [&](int e) -> i32x4 {
+        return (unsigned)e < (unsigned)nslots ? *(const i32x4*)(smem + OFF_TAB + e * 16) : i32x4{0, 0, 0, 0};
+    };
+    auto slot_of = [&](const i32x4& v) -> Slot {
+        return Slot{__builtin_amdgcn_readfirstlane(v[0]), __builtin_amdgcn_readfirstlane(v[1]), __builtin_amdgcn_readfirstlane(v[2])};
+    };
+    // the two slots a wave looks at in a step are read one step ahead, so their LDS latency lies under the barrier
+    constexpr int LAG_B = VERT ? 0 : LAGY;                            // 3x1 waves: the row to request; 1x3 waves: the row to finish
+    i32x4 nxt_me = slot_load(0 - LAG), nxt_b = slot_load(0 - LAG_B);
+    [[maybe_unused]] u32x4 rv[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+
+#ifdef ERF_DEBUG
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
+    for (int t = 0; t < nsteps; ++t) {
+        const Slot me = slot_of(nxt_me), sb = slot_of(nxt_b);
+        nxt_me = slot_load(t + 1 - LAG);
+        nxt_b = slot_load(t + 1 - LAG_B);
+        // ---- 1x3 waves: finish row t - LAGY (y = relu(y' + x), whole chunks to HBM) with the residual requested a step ago, then
+        //      request the residual of the row finished in the next step: both run under the 3x1 waves' matrix instructions
+        if constexpr (!VERT) {
+            if ((sb.fl & 4) && !NBS_DBG(4)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const i32x4 a = *(const i32x4*)(smem + OFF_Y + ((t - LAGY) & (NY - 1)) * ROWB + lfin + j * 8 * PIXB);
+                    float fa[8], fr[8];
+                    ChunkOps<T>::unpack(a, fa);
+                    ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, rv[j]), fr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fa[e] = fmaxf(fa[e] + fr[e], 0.f);
+                    const i32x4 o = ChunkOps<T>::pack(fa);
+                    const bool ok = pc + 8 * j >= 2 && pc + 8 * j < 2 + TW && sb.c0 - 2 + pc + 8 * j < p.W;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, ok ? gvoff + j * 8 * PIXB : ERF_OOB,
+                                                           (uint32_t)sb.soff, 0);
+                }
+                asm volatile("s_nop 4" ::: "memory");      // a buffer store's data registers must not be rewritten right after its issue
+            }
+            const Slot f = slot_of(nxt_b);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = (f.fl & 4) && pc + 8 * j >= 2 && pc + 8 * j < 2 + TW && f.c0 - 2 + pc + 8 * j < p.W;
+                rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? gvoff + j * 8 * PIXB : ERF_OOB, (uint32_t)f.soff, 0);
+            }
+        }
+        // ---- 3x1 waves: request x row t (always two operations, masked when there is nothing to fetch: the wait below counts them)
+        if constexpr (VERT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = (sb.fl & 8) && (unsigned)(sb.c0 - 2 + pc + 8 * j) < (unsigned)p.W && !NBS_DBG(8);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rs_x, (__attribute__((address_space(3))) void*)(smem + OFF_X + (t & (NX - 1)) * ROWB + PIXB + (2 * duty + j) * 1024), 16,
+                    ok ? gvoff + j * 8 * PIXB : ERF_OOB, (uint32_t)sb.soff, 0, 0);
+            }
+        }
+
+        NBS_STAMP(0)
+        // ---- this role's convolution on row t - LAG
+        constexpr int need = ROLE < 2 ? 2 : 4;
+        if (me.fl & need) {
+            char* dst;
+            if constexpr (ROLE == 0) dst = smem + OFF_A1 + ((t - LAG1) & (NA1 - 1)) * ROWB;
+            else if constexpr (ROLE == 1) dst = smem + OFF_A2 + ((t - LAG2) & (NA2 - 1)) * ROWB;
+            else if constexpr (ROLE == 2) dst = smem + OFF_A3 + ((t - LAG3) & (NA3 - 1)) * ROWB;
+            else dst = smem + OFF_Y + ((t - LAG4) & (NY - 1)) * ROWB;
+            if (ROLE == 1 && !(me.fl & 8)) {
+                // a2 rows outside the image are the zero padding of conv3x1_2
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{0, 0};
+            } else {
+                // fragment addresses of this step
+                int fa[6];
+                if constexpr (VERT) {
+                    const int src = ROLE == 0 ? OFF_X : OFF_A2;
+                    const int msk = ROLE == 0 ? NX - 1 : NA2 - 1;
+#pragma unroll
+                    for (int tap = 0; tap < 3; ++tap) {
+                        const int rb = src + ((t - LAG - 1 + tap) & msk) * ROWB;
+#pragma unroll
+                        for (int kc = 0; kc < 2; ++kc) fa[tap * 2 + kc] = fo[kc] + rb;
+                    }
+                } else {
+                    const int rb = ROLE == 1 ? OFF_A1 + ((t - LAG2) & (NA1 - 1)) * ROWB : OFF_A3 + ((t - LAG4) & (NA3 - 1)) * ROWB;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) fa[i] = fo[i] + rb;
+                }
+                i32x4 b0[KS], b1[KS];
+                if (NBS_DBG(16)) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) b0[ks] = b1[ks] = i32x4{fa[ks], 0, 0, 0};
+                } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) b0[ks] = lds_read_b128<0>(fa[ks]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) b1[ks] = lds_read_b128<16 * PIXB>(fa[ks]);
+                }
+                f32x4 acc[2][CT];
+                int cm[2];
+                if constexpr (VERT) {
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+                        cm[pt] = (unsigned)(me.c0 - 2 + 32 * half + 16 * pt + r16) < (unsigned)p.W ? -1 : 0;
+                }
+                auto epi = [&](auto pti) {
+                    constexpr int pt = decltype(pti)::value;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        f32x4 v = acc[pt][ct];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = v[e] * sc[ct][e] + sh[ct][e];
+                            if constexpr (ROLE != 3) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        i32x2 o = pack_bf16x4(v);
+                        if constexpr (VERT) { o[0] &= cm[pt]; o[1] &= cm[pt]; }
+                        *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = o;
+                    }
+                };
+                wait_lgkm<KS>();
+                NBS_STAMP(1)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) tie_reg(b0[ks]);
+                if (NBS_DBG(1)) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) { acc[0][ct] = __builtin_bit_cast(f32x4, b0[ct]); acc[1][ct] = __builtin_bit_cast(f32x4, b1[ct]); }
+                    wait_lgkm<0>();
+                } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[0][ct] = mma_step<T>(w[ct][ks], b0[ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[0][ct]);
+                wait_lgkm<0>();
+                NBS_STAMP(2)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) tie_reg(b1[ks]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[1][ct] = mma_step<T>(w[ct][ks], b1[ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[1][ct]);
+                }
+                if (!NBS_DBG(2)) {
+                epi(std::integral_constant<int, 0>{});
+                epi(std::integral_constant<int, 1>{});
+                }
+                NBS_STAMP(3)
+            }
+        }
+        if constexpr (!VERT) {
+            NBS_STAMP(4)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            NBS_STAMP(5)
+            asm volatile("s_barrier" ::: "memory");
+        } else {
+            NBS_STAMP(4)
+            // the x row requested D steps ago has landed (two requests per step, in order)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * D) : "memory");
+            NBS_STAMP(5)
+            asm volatile("s_barrier" ::: "memory");
+        }
+        NBS_STAMP(6)
+    }
+#ifdef ERF_DEBUG
+    if (NBS_DBG(256) && lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = g_nbs_stamps + (blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = st[i];
+        o[7] = __builtin_amdgcn_s_memtime() - tstart;
+    }
+#endif
+}
+
+}  // namespace nbs
+#endif
+
+__global__ __launch_bounds__(nbs::NTHREADS, 1)
+void nb1d_block64s_kernel(const NbStreamParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace nbs;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int o = tid * 16; o < OFF_TAB; o += NTHREADS * 16) *(i32x4*)(smem + o) = i32x4{0, 0, 0, 0};
+    // The slot table: this workgroup's rows are the run [L0, L1) of the linearised (image, strip, row) space, cut into chunks
+    // where it crosses into the next strip; a chunk of rc output rows starting at row r0 is rc + 4 slots (rows r0-2 .. r0+rc+1).
+    {
+        const int L0 = blockIdx.x * p.rows_per_wg;
+        int L1 = L0 + p.rows_per_wg;
+        if (L1 > p.rows_total) L1 = p.rows_total;
+        int nslots = 0;
+        if (L0 < L1) {
+            const int cid0 = L0 / p.H, r00 = L0 - cid0 * p.H;
+            const int rc0 = p.H - r00 < L1 - L0 ? p.H - r00 : L1 - L0;
+            nslots = (L1 - L0) + 4 * ((L1 - 1) / p.H - cid0 + 1);
+            for (int e = tid; e < nslots; e += NTHREADS) {
+                int k = 0, ci = e, r0 = r00, rc = rc0;
+                if (e >= rc0 + 4) {
+                    const int e2 = e - (rc0 + 4);
+                    k = 1 + e2 / (p.H + 4);
+                    ci = e2 - (k - 1) * (p.H + 4);
+                    r0 = 0;
+                    const int left = (L1 - L0) - rc0 - (k - 1) * p.H;
+                    rc = p.H < left ? p.H : left;
+                }
+                const int cid = cid0 + k, n = cid / p.S, st = cid - n * p.S;
+                const int h = r0 - 2 + ci, c0 = st * TW;
+                const int fl = 1 | ((ci >= 1 && ci < rc + 3) ? 2 : 0) | ((ci >= 2 && ci < rc + 2) ? 4 : 0) | ((h >= 0 && h < p.H) ? 8 : 0);
+                *(i32x4*)(smem + OFF_TAB + e * 16) = i32x4{((n * p.H + h) * p.W + c0) * PIXB, c0, fl, e == 0 ? nslots : 0};
+            }
+        } else if (tid == 0) {
+            *(i32x4*)(smem + OFF_TAB) = i32x4{0, 0, 0, 0};
+        }
+    }
+    ERF_LDS_BARRIER();
+    switch (wave >> 1) {
+        case 0: role_loop<0>(p, smem, wave, lane); break;
+        case 1: role_loop<1>(p, smem, wave, lane); break;
+        case 2: role_loop<3>(p, smem, wave, lane); break;
+        default: role_loop<2>(p, smem, wave, lane); break;
+    }
+#endif
+}
+
+int nb1d_block64s_launch(const void* x, void* y, const void* const* packed4, const float* tab, int dtype, int N, int H, int W, int C,
+                         int dilation, hipStream_t stream) {
+    using namespace nbs;
+    if (dtype != 1 || C != nbs::C || dilation != 1) return ERF_EUNSUPPORTED;
+    if (N < 1 || H < 1 || W < 1) return ERF_EINVAL;
+    NbStreamParams p{};
+    p.x = (const T*)x; p.y = (T*)y;
+    for (int i = 0; i < 4; ++i) p.w[i] = packed4[i];
+    p.tab = tab; p.N = N; p.H = H; p.W = W;
+    p.S = (W + TW - 1) / TW;
+    const long long rows = (long long)N * p.S * H;
+    // byte offsets are 32-bit, and a row two above / below an image may be addressed (masked) before it is clipped
+    const long long bytes = (long long)N * H * W * PIXB;
+    if (rows > 0x3FFFFFFF || bytes + (long long)(3 * W + FW) * PIXB >= 0x7FFFFFFFLL) return ERF_EUNSUPPORTED;
+    p.rows_total = (int)rows;
+    int grid = 256;
+    if (rows < 256LL * 8) grid = (int)((rows + 7) / 8);              // at least eight rows per workgroup
+    long long rpw = (rows + grid - 1) / grid;
+    while (rpw + 4 * ((rpw + H - 1) / H + 1) > MAX_SLOTS) rpw = rpw * 3 / 4;     // the slot table of a workgroup lives in LDS
+    p.rows_per_wg = (int)rpw;
+    grid = (int)((rows + rpw - 1) / rpw);
+    p.fH = make_fastdiv((uint32_t)H); p.fS = make_fastdiv((uint32_t)p.S);
+    p.bytes = (uint32_t)bytes;
+    p.dbg = erf_debug_env("ERF_BLOCK_DBG", 0);
+    if (hipFuncSetAttribute((const void*)nb1d_block64s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        return ERF_ELAUNCH;
+    hipLaunchKernelGGL(nb1d_block64s_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, stream, p);
+    return erf_check_launch();
+}
+
+#ifdef ERF_DEBUG
+// diagnostic builds only: the cycle stamps of the last launch, [256 workgroups][8 waves][8 sections] (section 7 = whole loop)
+extern "C" int erf_debug_block64s_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nbs_stamps), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -27,9 +27,3 @@ for fused in ((16, 64), ()):
   ts = sorted(ts[4:])
   print(f"{'one launch' if fused else 'two pair launches'}: median {ts[len(ts)//2]:.1f} us  min {ts[0]:.1f}", flush=True)
 print("bit-identical:", torch.equal(y, y_fused))
-y = y_fused
-import os
-if int(os.environ.get("ERF_BLOCK_DBG", "0")) & 256:
-    st = y.view(torch.int64).reshape(-1)[:512].reshape(256, 2).cpu().double()
-    cyc, real = st[:, 0], st[:, 1]
-    print(f"tile loop: cycles median {cyc.median():.0f} (min {cyc.min():.0f} max {cyc.max():.0f}); 100MHz ticks median {real.median():.0f}; clock {float((cyc / real).median()) * 0.1:.3f} GHz; per tile {float(cyc.median()) / 8:.0f} cycles")

@@ -73,6 +73,16 @@ def test_block_kernel_declines_what_it_does_not_cover():
     assert ops.nb1d_block(x16.float(), w16, c16["table"], 1) is None
 
 
+def test_registered_block_op_falls_back_to_the_pair_launches():
+    """torch.ops.erfnet_mi355.nb1d_block on a shape the one-launch kernels decline (dilation 2): the op issues the two
+    conv1d_pair launches itself instead of failing, so a module that routes a block through it keeps working."""
+    blk = _block(64, 2)
+    x = torch.relu(torch.randn(2, 24, 40, 64, generator=torch.Generator().manual_seed(3))).to(DEV, torch.bfloat16)
+    c = blk._cached(ops.dt(x))
+    y = torch.ops.erfnet_mi355.nb1d_block(x, c["w1"], c["w2"], c["w3"], c["w4"], c["table"], 2)
+    assert torch.equal(y, _run(blk, x, False))
+
+
 def test_block_kernel_vs_reference_golden():
     """The reference's own eval-mode output of a 64-channel dilation-1 block (g2_blocks.npz, written by tests/golden/make_golden.py
     from train/erfnet.py's module), through the one-launch kernel; the bf16 bar is the one the default path is held to."""
