@@ -59,6 +59,9 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
+FUSE_BLOCKS_FLAG = ""
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +87,8 @@ def parse():
     ap.add_argument("--infer-steps", type=int, default=30, help="N > 1: steps of the inference leg reported beside the training headline")
     ap.add_argument("--infer-warmup", type=int, default=5)
     ap.add_argument("--no-fp32", action="store_true", help="auto mode at N = 1: skip the fp32 legs")
+    ap.add_argument("--fuse-blocks", default="", help="inference: channel counts whose dilation-1 blocks run as one launch, e.g. 16,64 "
+                                                     "(default: the package's erfnet.FUSE_BLOCKS)")
     return ap.parse_args()
 
 
@@ -175,6 +180,8 @@ def max_over_ranks(x: float, world, dev) -> float:
 
 def build_model(dev, dtype_name, classes=20):
     from erfnet_pytorch_amd import erfnet as E, synthetic as S
+    if FUSE_BLOCKS_FLAG:
+        E.FUSE_BLOCKS = tuple(int(c) for c in FUSE_BLOCKS_FLAG.split(","))
     model = E.ERFNet(classes)
     S.load_synthetic(model)
     model = model.to(dev).eval()
@@ -515,7 +522,9 @@ def add_measured_peaks(res, dev):
 
 
 def main():
+    global FUSE_BLOCKS_FLAG
     args = parse()
+    FUSE_BLOCKS_FLAG = args.fuse_blocks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
     if not torch.cuda.is_available():

@@ -276,25 +276,20 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
                 for (int ks = 0; ks < KS; ++ks) b1[ks] = lds_read_b128<16 * PIXB>(fa[ks]);
                 }
                 f32x4 acc[2][CT];
-                int cm[2];
-                if constexpr (VERT) {
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
-                        cm[pt] = (unsigned)(me.c0 - 2 + 32 * half + 16 * pt + r16) < (unsigned)p.W ? -1 : 0;
-                }
                 auto epi = [&](auto pti) {
                     constexpr int pt = decltype(pti)::value;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
                         f32x4 v = acc[pt][ct];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = v[e] * sc[ct][e] + sh[ct][e];
-                            if constexpr (ROLE != 3) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[ct][e] + sh[ct][e];
+                        // scalars, not vector elements: a bit cast of a vector ELEMENT misreads with this compiler
+                        int o0 = pack_bf16x2(v[0], v[1]), o1 = pack_bf16x2(v[2], v[3]);
+                        if constexpr (ROLE != 3) {         // ReLU on the rounded pairs: one instruction per two values, same bits
+                            o0 = relu_bf16x2(o0);
+                            o1 = relu_bf16x2(o1);
                         }
-                        i32x2 o = pack_bf16x4(v);
-                        if constexpr (VERT) { o[0] &= cm[pt]; o[1] &= cm[pt]; }
-                        *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = o;
+                        *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{o0, o1};
                     }
                 };
                 wait_lgkm<KS>();
@@ -324,6 +319,19 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
                 if (!NBS_DBG(2)) {
                 epi(std::integral_constant<int, 0>{});
                 epi(std::integral_constant<int, 1>{});
+                }
+                if constexpr (VERT) {
+                    // columns of the frame outside the image (first / last strip only; wave-uniform and rare): a1 / a3 are zero
+                    // there -- the next convolution's zero padding.  The zeros follow the values through the same, ordered, queue.
+                    if (me.c0 < 2 || me.c0 - 2 + FW > p.W) {
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) {
+                            if ((unsigned)(me.c0 - 2 + 32 * half + 16 * pt + r16) >= (unsigned)p.W) {
+#pragma unroll
+                                for (int ct = 0; ct < CT; ++ct) *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{0, 0};
+                            }
+                        }
+                    }
                 }
                 NBS_STAMP(3)
             }
@@ -418,8 +426,10 @@ int nb1d_block64s_launch(const void* x, void* y, const void* const* packed4, con
     const long long bytes = (long long)N * H * W * PIXB;
     if (rows > 0x3FFFFFFF || bytes + (long long)(3 * W + FW) * PIXB >= 0x7FFFFFFFLL) return ERF_EUNSUPPORTED;
     p.rows_total = (int)rows;
+    // A workgroup's pipeline takes 9 steps to fill and drain and 4 steps of halo per chunk, whatever the length of its run: below
+    // 40 rows per workgroup it is better to use fewer CUs (and leave the rest to whatever else runs on the device).
     int grid = 256;
-    if (rows < 256LL * 8) grid = (int)((rows + 7) / 8);              // at least eight rows per workgroup
+    if (rows < 256LL * 40) grid = (int)((rows + 39) / 40);
     long long rpw = (rows + grid - 1) / grid;
     while (rpw + 4 * ((rpw + H - 1) / H + 1) > MAX_SLOTS) rpw = rpw * 3 / 4;     // the slot table of a workgroup lives in LDS
     p.rows_per_wg = (int)rpw;

@@ -24,9 +24,9 @@ from ._lib import AXIS_H, AXIS_W, BF16, F32
 
 BN_EPS = 1e-3
 FUSE_PAIRS = True     # inference: one launch per conv3x1 -> conv1x3 pair where the library supports it
-# inference: channel counts whose dilation-1 non_bottleneck_1d blocks run as ONE launch (bit-identical to the pair path).
-# 64 is supported but measured slower than two pair launches, so it stays opt-in: FUSE_BLOCKS = (16, 64).
-FUSE_BLOCKS = (16,)
+# inference: channel counts whose dilation-1 non_bottleneck_1d blocks run as ONE launch (bit-identical to the pair path):
+# 16 (one workgroup per tile, csrc/nb1d_block16.hip) and 64 (a stream of rows through four wave roles, csrc/nb1d_block64s.hip).
+FUSE_BLOCKS = (16, 64)
 
 
 _SIDE_STREAMS = {}       # device index -> side streams of ERFNet.predict_labels(ways=k)

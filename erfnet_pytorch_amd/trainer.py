@@ -252,7 +252,9 @@ class Trainer:
         self.gflat.zero_()
 
     def step(self, images, targets):
-        """images [N,3,H,W]; targets [N,1,H,W] or [N,H,W] int64.  Returns (global loss tensor, logits or None)."""
+        """images [N,3,H,W] (fp32 / bf16, or uint8 [N,3,H,W] / [N,H,W,3]: ToTensor()'s / 255 is then applied by the initial
+        block); targets [N,1,H,W] or [N,H,W] int64.  Returns (global loss tensor, logits or None).  In graph modes the loss is a
+        copy; returned logits alias a static buffer that the next step overwrites (clone them to keep them)."""
         if targets.dim() == 4:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
         self._sync_lr()
@@ -538,7 +540,7 @@ class ArenaSGD:
         self._epoch[0] += 1
         self.step_count += 1
         ops.bump_param_epoch()
-        return loss, outputs
+        return loss.clone(), outputs                                  # the logits alias a static buffer the next replay overwrites
 
     def _step_eager(self, images, targets):
         self.zero_grad()
