@@ -16,17 +16,18 @@
 //
 // The unit of work is one row of a column STRIP: a frame of 64 columns (local column c = image column - c0 + 2) of which
 // 60 are output columns (c in [2, 62)); the two columns either side are the halo the two 1x3 convolutions need and are
-// recomputed by the neighbouring strip.  A workgroup marches down its strip one row per step, all roles working at once on
+// recomputed by the neighbouring strip.  When an image's last strip has at most 28 output columns it is a NARROW strip: a
+// frame of 32 columns, one matrix tile per wave instead of two (W = 256: four wide strips and a narrow one).  A workgroup marches down its strip one row per step, all roles working at once on
 // different rows -- the vertical halo of the two 3x1 convolutions costs nothing, their three taps are simply the three
 // youngest rows of a ring buffer:
 //
-//   step t:  DMA       x row t  requested -> X[t % 8]; it is first read D = 2 steps after the step of its request
+//   step t:  DMA       x row t  requested -> X[t % 8]; it is first read D + 1 = 2 steps later
 //            conv3x1_1 a1 row u = t-2-D  from X[u-1], X[u], X[u+1]       -> A1[u % 2]
 //            conv1x3_1 a2 row u = t-3-D  from A1[u % 2]                   -> A2[u % 4]   (zeros for rows outside the image)
 //            conv3x1_2 a3 row u = t-5-D  from A2[u-1], A2[u], A2[u+1]     -> A3[u % 2]
 //            conv1x3_2 y' row u = t-6-D  from A3[u % 2]                   -> Y[u % 2]    (bf16(s4 * acc + t4), staged)
 //            finish    y  row u = t-7-D  = relu(Y[u % 2] + x row u)       -> HBM as whole 16-byte chunks; x is re-read from
-//                                            global memory (an L2 hit: this CU fetched the row nine steps ago), requested one
+//                                            global memory (an L2 hit: this CU fetched the row eight steps ago), requested one
 //                                            step ahead
 //   one workgroup barrier per step.  The x requests are issued by the four 3x1 waves (2 KB each), the rows are finished by
 //   the four 1x3 waves (16 pixels each): a wave's memory operations complete in order, so a wave that waits for an L2 hit
@@ -37,8 +38,8 @@
 // pixel XOR-swizzled by the slot index so that a fragment read (16 consecutive pixels, one chunk per quarter wave) is free
 // of bank conflicts.  18 rows = 152 KB of LDS.
 //
-// A workgroup's rows are a contiguous run of the linearised (image, strip, row) space, cut where it crosses into the next
-// strip; each piece ("chunk") of RC output rows takes RC + 4 steps (rows r0-2 .. r0+RC+1 are loaded, a1 / a2 are formed
+// A workgroup's rows are a contiguous run of the linearised (image, strip, row) space (the runs are cut by the host so that
+// every workgroup has about the same number of steps), cut where it crosses into the next strip; each piece ("chunk") of RC output rows takes RC + 4 steps (rows r0-2 .. r0+RC+1 are loaded, a1 / a2 are formed
 // on RC + 2 of them), and the roles simply keep stepping from one chunk into the next, so the pipeline fills and drains
 // once per workgroup, not once per chunk.  Intermediate values outside the image are forced to zero where the next
 // convolution pads with zeros: a1 and a3 in columns outside the image, a2 in rows outside the image; x outside the image
@@ -66,11 +67,13 @@ constexpr int OFF_Y = OFF_A3 + NA3 * ROWB;
 constexpr int OFF_TAB = OFF_Y + NY * ROWB;          // 152064: the slot table, 16 bytes per slot
 constexpr int MAX_SLOTS = 700;
 constexpr int LDS_BYTES = OFF_TAB + MAX_SLOTS * 16; // 163264
-constexpr int D = 2;                                // steps between the request of an x row and its first use
+constexpr int D = 1;                                // steps between the request of an x row and its first use
 constexpr int LAG1 = 2 + D, LAG2 = 3 + D, LAG3 = 5 + D, LAG4 = 6 + D, LAGY = 7 + D;
 static_assert(NX >= 4 + D && (NX & (NX - 1)) == 0, "an x row lives from its request to its last use as a conv3x1_1 tap");
 constexpr int PAD = 2 * PIXB;                       // the descriptors start two pixels before the tensors (column c0 - 2 of strip 0)
 constexpr int NTHREADS = 512;
+constexpr int FWN = 32, TWN = 28;                   // frame / output columns of a narrow strip
+constexpr int MAX_WGS = 256;
 static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES % 16 == 0, "ring buffers fit the CU's LDS");
 }  // namespace nbs
 
@@ -80,10 +83,9 @@ struct NbStreamParams {
     const void* w[4];
     const float* tab;        // [4 convolutions][scale | shift][64] fp32
     int N, H, W, S;          // S = strips per image
-    int rows_total;          // N * S * H
-    int rows_per_wg;
-    FastDiv fH, fS;
+    int narrow_last;         // the last strip of an image is a narrow one (32-column frame, 28 output columns)
     uint32_t bytes;          // N*H*W*128
+    int l0[nbs::MAX_WGS + 1];     // workgroup b runs rows [l0[b], l0[b + 1]) of the linearised (image, strip, row) space
     int dbg;                 // -DERF_DEBUG builds only (ERF_BLOCK_DBG): 1 no matrix instructions, 2 no epilogue, 4 no row finishing,
                              // 8 no x requests, 16 no fragment reads, 256 cycle stamps
 };
@@ -105,7 +107,10 @@ namespace nbs {
 struct Slot {
     int soff;    // byte offset of (image, row, column c0) from the tensor = of column c0 - 2 from the descriptor base
     int c0;      // first output column of the strip
-    int fl;      // 1: slot exists, 2: a1 / a2 are formed on this row, 4: a3 / y are formed on this row, 8: row inside the image
+    int fl;      // 1: slot exists, 2: a1 / a2 are formed on this row, 4: a3 / y are formed on this row, 8: row inside the image,
+                 // 16: narrow strip
+    __device__ __forceinline__ int fw() const { return (fl & 16) ? FWN : FW; }
+    __device__ __forceinline__ int tw() const { return (fl & 16) ? TWN : TW; }
 };
 
 template <int ROLE>
@@ -207,7 +212,7 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
 #pragma unroll
                     for (int e = 0; e < 8; ++e) fa[e] = fmaxf(fa[e] + fr[e], 0.f);
                     const i32x4 o = ChunkOps<T>::pack(fa);
-                    const bool ok = pc + 8 * j >= 2 && pc + 8 * j < 2 + TW && sb.c0 - 2 + pc + 8 * j < p.W;
+                    const bool ok = pc + 8 * j >= 2 && pc + 8 * j < 2 + sb.tw() && sb.c0 - 2 + pc + 8 * j < p.W;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, ok ? gvoff + j * 8 * PIXB : ERF_OOB,
                                                            (uint32_t)sb.soff, 0);
                 }
@@ -218,7 +223,7 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
             const Slot f = slot_of(nxt_b);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bool ok = (f.fl & 4) && pc + 8 * j >= 2 && pc + 8 * j < 2 + TW && f.c0 - 2 + pc + 8 * j < p.W;
+                const bool ok = (f.fl & 4) && pc + 8 * j >= 2 && pc + 8 * j < 2 + f.tw() && f.c0 - 2 + pc + 8 * j < p.W;
                 rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? gvoff + j * 8 * PIXB : ERF_OOB, (uint32_t)f.soff, 0);
             }
         }
@@ -226,7 +231,7 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
         if constexpr (VERT) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bool ok = (sb.fl & 8) && (unsigned)(sb.c0 - 2 + pc + 8 * j) < (unsigned)p.W && !NBS_DBG(8);
+                const bool ok = (sb.fl & 8) && pc + 8 * j < sb.fw() && (unsigned)(sb.c0 - 2 + pc + 8 * j) < (unsigned)p.W && !NBS_DBG(8);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rs_x, (__attribute__((address_space(3))) void*)(smem + OFF_X + (t & (NX - 1)) * ROWB + PIXB + (2 * duty + j) * 1024), 16,
                     ok ? gvoff + j * 8 * PIXB : ERF_OOB, (uint32_t)sb.soff, 0, 0);
@@ -236,105 +241,121 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
         NBS_STAMP(0)
         // ---- this role's convolution on row t - LAG
         constexpr int need = ROLE < 2 ? 2 : 4;
-        if (me.fl & need) {
+        // A narrow strip has one matrix tile per wave instead of two: tile `half` of the frame, i.e. this lane's usual slot minus
+        // 16 half slots (the swizzle key, slot & 7, is the same).  Two copies of the code, so that the wide one keeps its registers.
+        auto conv = [&](auto narrow_c) {
+            constexpr bool NARROW = decltype(narrow_c)::value;
+            const int shift = NARROW ? half * 16 * PIXB : 0;
             char* dst;
-            if constexpr (ROLE == 0) dst = smem + OFF_A1 + ((t - LAG1) & (NA1 - 1)) * ROWB;
-            else if constexpr (ROLE == 1) dst = smem + OFF_A2 + ((t - LAG2) & (NA2 - 1)) * ROWB;
-            else if constexpr (ROLE == 2) dst = smem + OFF_A3 + ((t - LAG3) & (NA3 - 1)) * ROWB;
-            else dst = smem + OFF_Y + ((t - LAG4) & (NY - 1)) * ROWB;
+            if constexpr (ROLE == 0) dst = smem + OFF_A1 + ((t - LAG1) & (NA1 - 1)) * ROWB - shift;
+            else if constexpr (ROLE == 1) dst = smem + OFF_A2 + ((t - LAG2) & (NA2 - 1)) * ROWB - shift;
+            else if constexpr (ROLE == 2) dst = smem + OFF_A3 + ((t - LAG3) & (NA3 - 1)) * ROWB - shift;
+            else dst = smem + OFF_Y + ((t - LAG4) & (NY - 1)) * ROWB - shift;
             if (ROLE == 1 && !(me.fl & 8)) {
                 // a2 rows outside the image are the zero padding of conv3x1_2
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
+                for (int pt = 0; pt < (NARROW ? 1 : 2); ++pt)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{0, 0};
-            } else {
-                // fragment addresses of this step
-                int fa[6];
-                if constexpr (VERT) {
-                    const int src = ROLE == 0 ? OFF_X : OFF_A2;
-                    const int msk = ROLE == 0 ? NX - 1 : NA2 - 1;
+                return;
+            }
+            // fragment addresses of this step
+            int fa[6];
+            if constexpr (VERT) {
+                const int src = ROLE == 0 ? OFF_X : OFF_A2;
+                const int msk = ROLE == 0 ? NX - 1 : NA2 - 1;
 #pragma unroll
-                    for (int tap = 0; tap < 3; ++tap) {
-                        const int rb = src + ((t - LAG - 1 + tap) & msk) * ROWB;
+                for (int tap = 0; tap < 3; ++tap) {
+                    const int rb = src + ((t - LAG - 1 + tap) & msk) * ROWB - shift;
 #pragma unroll
-                        for (int kc = 0; kc < 2; ++kc) fa[tap * 2 + kc] = fo[kc] + rb;
-                    }
-                } else {
-                    const int rb = ROLE == 1 ? OFF_A1 + ((t - LAG2) & (NA1 - 1)) * ROWB : OFF_A3 + ((t - LAG4) & (NA3 - 1)) * ROWB;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) fa[i] = fo[i] + rb;
+                    for (int kc = 0; kc < 2; ++kc) fa[tap * 2 + kc] = fo[kc] + rb;
                 }
-                i32x4 b0[KS], b1[KS];
-                if (NBS_DBG(16)) {
+            } else {
+                const int rb = (ROLE == 1 ? OFF_A1 + ((t - LAG2) & (NA1 - 1)) * ROWB : OFF_A3 + ((t - LAG4) & (NA3 - 1)) * ROWB) - shift;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) b0[ks] = b1[ks] = i32x4{fa[ks], 0, 0, 0};
-                } else {
+                for (int i = 0; i < 6; ++i) fa[i] = fo[i] + rb;
+            }
+            i32x4 b0[KS];
+            [[maybe_unused]] i32x4 b1[KS];
+            if (NBS_DBG(16)) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) b0[ks] = b1[ks] = i32x4{fa[ks], 0, 0, 0};
+            } else {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) b0[ks] = lds_read_b128<0>(fa[ks]);
+                if constexpr (!NARROW) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) b1[ks] = lds_read_b128<16 * PIXB>(fa[ks]);
+                    for (int ks = 0; ks < KS; ++ks) b1[ks] = lds_read_b128<16 * PIXB>(fa[ks]);
                 }
-                f32x4 acc[2][CT];
-                auto epi = [&](auto pti) {
-                    constexpr int pt = decltype(pti)::value;
+            }
+            f32x4 acc[NARROW ? 1 : 2][CT];
+            auto epi = [&](auto pti) {
+                constexpr int pt = decltype(pti)::value;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        f32x4 v = acc[pt][ct];
+                for (int ct = 0; ct < CT; ++ct) {
+                    f32x4 v = acc[pt][ct];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[ct][e] + sh[ct][e];
-                        // scalars, not vector elements: a bit cast of a vector ELEMENT misreads with this compiler
-                        int o0 = pack_bf16x2(v[0], v[1]), o1 = pack_bf16x2(v[2], v[3]);
-                        if constexpr (ROLE != 3) {         // ReLU on the rounded pairs: one instruction per two values, same bits
-                            o0 = relu_bf16x2(o0);
-                            o1 = relu_bf16x2(o1);
-                        }
-                        *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{o0, o1};
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[ct][e] + sh[ct][e];
+                    // scalars, not vector elements: a bit cast of a vector ELEMENT misreads with this compiler
+                    int o0 = pack_bf16x2(v[0], v[1]), o1 = pack_bf16x2(v[2], v[3]);
+                    if constexpr (ROLE != 3) {         // ReLU on the rounded pairs: one instruction per two values, same bits
+                        o0 = relu_bf16x2(o0);
+                        o1 = relu_bf16x2(o1);
                     }
-                };
-                wait_lgkm<KS>();
-                NBS_STAMP(1)
+                    *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{o0, o1};
+                }
+            };
+            wait_lgkm<NARROW ? 0 : KS>();
+            NBS_STAMP(1)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) tie_reg(b0[ks]);
-                if (NBS_DBG(1)) {
+            for (int ks = 0; ks < KS; ++ks) tie_reg(b0[ks]);
+            if (NBS_DBG(1)) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) { acc[0][ct] = __builtin_bit_cast(f32x4, b0[ct]); acc[1][ct] = __builtin_bit_cast(f32x4, b1[ct]); }
-                    wait_lgkm<0>();
-                } else {
+                for (int pt = 0; pt < (NARROW ? 1 : 2); ++pt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = __builtin_bit_cast(f32x4, b0[ct]);
+                wait_lgkm<0>();
+            } else {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         acc[0][ct] = mma_step<T>(w[ct][ks], b0[ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[0][ct]);
-                wait_lgkm<0>();
-                NBS_STAMP(2)
+                if constexpr (!NARROW) {
+                    wait_lgkm<0>();
+                    NBS_STAMP(2)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) tie_reg(b1[ks]);
+                    for (int ks = 0; ks < KS; ++ks) tie_reg(b1[ks]);
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[1][ct] = mma_step<T>(w[ct][ks], b1[ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[1][ct]);
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[1][ct] = mma_step<T>(w[ct][ks], b1[ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[1][ct]);
                 }
-                if (!NBS_DBG(2)) {
+            }
+            if (!NBS_DBG(2)) {
                 epi(std::integral_constant<int, 0>{});
-                epi(std::integral_constant<int, 1>{});
-                }
-                if constexpr (VERT) {
-                    // columns of the frame outside the image (first / last strip only; wave-uniform and rare): a1 / a3 are zero
-                    // there -- the next convolution's zero padding.  The zeros follow the values through the same, ordered, queue.
-                    if (me.c0 < 2 || me.c0 - 2 + FW > p.W) {
+                if constexpr (!NARROW) epi(std::integral_constant<int, 1>{});
+            }
+            if constexpr (VERT) {
+                // columns of the frame outside the image (first / last strip only; wave-uniform and rare): a1 / a3 are zero
+                // there -- the next convolution's zero padding.  The zeros follow the values through the same, ordered, queue.
+                if (me.c0 < 2 || me.c0 - 2 + (NARROW ? FWN : FW) > p.W) {
+                    const int cbase = me.c0 - 2 + (NARROW ? 16 : 32) * half + r16;
 #pragma unroll
-                        for (int pt = 0; pt < 2; ++pt) {
-                            if ((unsigned)(me.c0 - 2 + 32 * half + 16 * pt + r16) >= (unsigned)p.W) {
+                    for (int pt = 0; pt < (NARROW ? 1 : 2); ++pt) {
+                        if ((unsigned)(cbase + 16 * pt) >= (unsigned)p.W) {
 #pragma unroll
-                                for (int ct = 0; ct < CT; ++ct) *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{0, 0};
-                            }
+                            for (int ct = 0; ct < CT; ++ct) *(i32x2*)(dst + wo[ct] + pt * 16 * PIXB) = i32x2{0, 0};
                         }
                     }
                 }
-                NBS_STAMP(3)
             }
+            NBS_STAMP(3)
+        };
+        if (me.fl & need) {
+            if (me.fl & 16) conv(std::true_type{});
+            else conv(std::false_type{});
         }
         if constexpr (!VERT) {
             NBS_STAMP(4)
@@ -374,9 +395,7 @@ void nb1d_block64s_kernel(const NbStreamParams p) {
     // The slot table: this workgroup's rows are the run [L0, L1) of the linearised (image, strip, row) space, cut into chunks
     // where it crosses into the next strip; a chunk of rc output rows starting at row r0 is rc + 4 slots (rows r0-2 .. r0+rc+1).
     {
-        const int L0 = blockIdx.x * p.rows_per_wg;
-        int L1 = L0 + p.rows_per_wg;
-        if (L1 > p.rows_total) L1 = p.rows_total;
+        const int L0 = p.l0[blockIdx.x], L1 = p.l0[blockIdx.x + 1];
         int nslots = 0;
         if (L0 < L1) {
             const int cid0 = L0 / p.H, r00 = L0 - cid0 * p.H;
@@ -394,7 +413,8 @@ void nb1d_block64s_kernel(const NbStreamParams p) {
                 }
                 const int cid = cid0 + k, n = cid / p.S, st = cid - n * p.S;
                 const int h = r0 - 2 + ci, c0 = st * TW;
-                const int fl = 1 | ((ci >= 1 && ci < rc + 3) ? 2 : 0) | ((ci >= 2 && ci < rc + 2) ? 4 : 0) | ((h >= 0 && h < p.H) ? 8 : 0);
+                const int fl = 1 | ((ci >= 1 && ci < rc + 3) ? 2 : 0) | ((ci >= 2 && ci < rc + 2) ? 4 : 0) | ((h >= 0 && h < p.H) ? 8 : 0) |
+                               ((p.narrow_last && st == p.S - 1) ? 16 : 0);
                 *(i32x4*)(smem + OFF_TAB + e * 16) = i32x4{((n * p.H + h) * p.W + c0) * PIXB, c0, fl, e == 0 ? nslots : 0};
             }
         } else if (tid == 0) {
@@ -420,22 +440,68 @@ int nb1d_block64s_launch(const void* x, void* y, const void* const* packed4, con
     p.x = (const T*)x; p.y = (T*)y;
     for (int i = 0; i < 4; ++i) p.w[i] = packed4[i];
     p.tab = tab; p.N = N; p.H = H; p.W = W;
-    p.S = (W + TW - 1) / TW;
+    // strips: 60 output columns each; a remainder of at most 28 columns is a narrow strip (half the matrix work per row)
+    const int wide = W / TW, rest = W - wide * TW;
+    p.S = wide + (rest > 0);
+    p.narrow_last = rest > 0 && rest <= TWN && erf_debug_env("ERF_NBS_NARROW", 1);         // (the switch exists in debug builds only)
     const long long rows = (long long)N * p.S * H;
     // byte offsets are 32-bit, and a row two above / below an image may be addressed (masked) before it is clipped
     const long long bytes = (long long)N * H * W * PIXB;
     if (rows > 0x3FFFFFFF || bytes + (long long)(3 * W + FW) * PIXB >= 0x7FFFFFFFLL) return ERF_EUNSUPPORTED;
-    p.rows_total = (int)rows;
-    // A workgroup's pipeline takes 9 steps to fill and drain and 4 steps of halo per chunk, whatever the length of its run: below
-    // 40 rows per workgroup it is better to use fewer CUs (and leave the rest to whatever else runs on the device).
-    int grid = 256;
-    if (rows < 256LL * 40) grid = (int)((rows + 39) / 40);
-    long long rpw = (rows + grid - 1) / grid;
-    while (rpw + 4 * ((rpw + H - 1) / H + 1) > MAX_SLOTS) rpw = rpw * 3 / 4;     // the slot table of a workgroup lives in LDS
-    p.rows_per_wg = (int)rpw;
-    grid = (int)((rows + rpw - 1) / rpw);
-    p.fH = make_fastdiv((uint32_t)H); p.fS = make_fastdiv((uint32_t)p.S);
     p.bytes = (uint32_t)bytes;
+    // Partition of the linearised (image, strip, row) space into at most MAX_WGS runs of about equal COST: a row of a wide strip
+    // costs one step, a row of a narrow strip NARROW_COST of one (measured: a step is mostly fixed cost -- slot decode, LDS
+    // latency, the barrier -- so half the matrix work saves only ~15 %; sweeping the constant over 0.5 .. 1.0 put the best
+    // batch time at 0.8 .. 1.0), every chunk (a run's part inside one strip) four more rows of halo, every run the pipeline's
+    // fill and drain.  A workgroup's pipeline takes LAGY steps to fill and drain whatever the length of its run: below 40 rows
+    // per workgroup it is better to use fewer CUs (and leave the rest to whatever else runs on the device).
+    if (rows > (long long)MAX_WGS * (MAX_SLOTS - 8)) return ERF_EUNSUPPORTED;     // more rows than 256 slot tables hold
+    const double NARROW_COST = erf_debug_env("ERF_NBS_NARROW_COST", 850) * 1e-3;
+    int want = MAX_WGS;
+    if (rows < (long long)MAX_WGS * 40) want = (int)((rows + 39) / 40);
+    const long long ncols = (long long)N * p.S;
+    auto col_cost = [&](long long cid) { return (p.narrow_last && cid % p.S == p.S - 1) ? NARROW_COST : 1.0; };
+    double total = 0;
+    for (long long c = 0; c < ncols; ++c) total += col_cost(c) * (H + 4);
+    // the partition depends on the shape only: the last one is remembered per thread (a replayed graph never comes here)
+    static thread_local struct { int N, H, W, grid; int l0[MAX_WGS + 1]; } memo = {0, 0, 0, 0, {0}};
+    int grid = 0;
+    if (memo.N == N && memo.H == H && memo.W == W) {
+        grid = memo.grid;
+        for (int b = 0; b <= MAX_WGS; ++b) p.l0[b] = memo.l0[b];
+    } else {
+    int tries = 0;
+    for (double target = total / want;; target *= 1.02) {
+        if (++tries > 1000) return ERF_EUNSUPPORTED;
+        // greedy: fill a run up to `target`, never beyond MAX_SLOTS table entries
+        grid = 0;
+        long long row = 0;
+        bool ok = true;
+        while (row < rows) {
+            if (grid == MAX_WGS) { ok = false; break; }
+            p.l0[grid++] = (int)row;
+            double cost = 0;
+            int slots = 0;
+            while (row < rows) {
+                const long long cid = row / H;
+                const int left = (int)((cid + 1) * H - row);                    // rows to the end of this strip
+                const double w = col_cost(cid);
+                int take = (int)((target - cost - 4 * w) / w);
+                if (take > left) take = left;
+                if (take > MAX_SLOTS - slots - 4) take = MAX_SLOTS - slots - 4;
+                if (take < 1) {
+                    if (cost == 0) take = 1; else break;                        // a run holds at least one row
+                }
+                row += take; cost += (take + 4) * w; slots += take + 4;
+                if (take < left) break;                                         // the run is full
+            }
+        }
+        if (ok && grid <= want) break;                                  // never more runs than asked for: a run holds a whole CU
+    }
+    for (int b = grid; b <= MAX_WGS; ++b) p.l0[b] = (int)rows;
+    memo.N = N; memo.H = H; memo.W = W; memo.grid = grid;
+    for (int b = 0; b <= MAX_WGS; ++b) memo.l0[b] = p.l0[b];
+    }
     p.dbg = erf_debug_env("ERF_BLOCK_DBG", 0);
     if (hipFuncSetAttribute((const void*)nb1d_block64s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
         return ERF_ELAUNCH;
