@@ -227,34 +227,49 @@ def measured_traffic(kernel_prefix, pixels):
 def roofline_infer(model, x, dtype_name):
     """Time the dominant kernel of one forward alone, with events on the launch stream.
 
-    bf16: the fused conv3x1->conv1x3 pair kernel on the 64-channel blocks (14 launches per forward, the
-    largest share of the step).  Its arithmetic intensity (2*2*3*C*C flop per pixel over 2..3 x C*2 bytes
-    = 154..192 flop/B) is below the MI355X ridge (2500 TFLOP/s / 8 TB/s = 312 flop/B): HBM-bound.
-    Algorithmic bytes per launch = input tensor + output tensor (+ the residual tensor for the second
-    pair of a block), each N*H/4*W/4*64*2 bytes.
+    bf16: the 64-channel non_bottleneck_1d blocks (7 per forward, the largest share of the step): by default one launch
+    per block (nb1d_block64s_kernel: x in, y out = 2 tensors of N*H/4*W/4*64*2 bytes for 4*2*3*C*C flop per pixel, 384
+    flop/B -- just above the MI355X ridge of 2500 TFLOP/s / 8 TB/s = 312 flop/B, priced against HBM like the two-launch
+    form it replaces, with the matrix rate beside it); with 64 not in erfnet.FUSE_BLOCKS two conv1d_pair launches per block
+    (154..192 flop/B, HBM-bound: input + output (+ the residual tensor for the second pair)).
     fp32: the single factorized convolution on the 128-channel blocks (MFMA-bound, 32 launches)."""
     from erfnet_pytorch_amd import ops
     from erfnet_pytorch_amd._lib import AXIS_H, AXIS_W
     n, _, h, w = x.shape
+    from erfnet_pytorch_amd import erfnet as E
+    fused = dtype_name == "bf16" and 64 in E.FUSE_BLOCKS
     if dtype_name == "bf16":
         hh, ww, c = h // 4, w // 4, 64
         # block inputs are ReLU outputs in the network (about half zeros): the probe tensor has the same statistics
         feat = torch.relu(torch.randn(n, hh, ww, c, device=x.device)).to(torch.bfloat16)
         mid, out = torch.empty_like(feat), torch.empty_like(feat)
         blocks = [m for m in list(model.encoder.layers) + list(model.decoder.layers) if getattr(m, "chann", 0) == 64]
-        plan = []
-        for blk in blocks:
-            cc = blk._cached(ops.dt(feat))
-            plan += [(feat, mid, cc["w1"], cc["t1"], cc["w2"], cc["s2"], cc["t2"], None, 1),
-                     (mid, out, cc["w3"], cc["t3"], cc["w4"], cc["s4"], cc["t4"], feat, blk.dilated)]
-        def run():
-            for (src, dst, wa, ta, wb, sb, tb, r, d) in plan:
-                if ops.conv1d_pair(src, wa, ta, wb, sb, tb, r, d, True, out=dst) is None:
-                    raise RuntimeError("pair kernel declined the benchmark shape")
         tensor_bytes = feat.numel() * 2
-        bytes_per_launch = sum(tensor_bytes * (3 if r is not None else 2) for (*_, r, _d) in plan) / len(plan)
-        flop = 2 * 2.0 * 3 * c * c * n * hh * ww
-        name = "conv1d_pair_kernel<64> (fused conv3x1+conv1x3, 64-channel blocks)"
+        plan = []
+        if fused:
+            # the whole block in one launch (csrc/nb1d_block64s.hip): x in, y out
+            for blk in blocks:
+                cc = blk._cached(ops.dt(feat))
+                plan.append(((cc["w1"], cc["w2"], cc["w3"], cc["w4"]), cc["table"]))
+            def run():
+                for (w4, table) in plan:
+                    if ops.nb1d_block(feat, w4, table, 1, out=out) is None:
+                        raise RuntimeError("block kernel declined the benchmark shape")
+            bytes_per_launch = 2.0 * tensor_bytes
+            flop = 4 * 2.0 * 3 * c * c * n * hh * ww
+            name = "nb1d_block64s_kernel (whole non_bottleneck_1d block, 64 channels, one launch)"
+        else:
+            for blk in blocks:
+                cc = blk._cached(ops.dt(feat))
+                plan += [(feat, mid, cc["w1"], cc["t1"], cc["w2"], cc["s2"], cc["t2"], None, 1),
+                         (mid, out, cc["w3"], cc["t3"], cc["w4"], cc["s4"], cc["t4"], feat, blk.dilated)]
+            def run():
+                for (src, dst, wa, ta, wb, sb, tb, r, d) in plan:
+                    if ops.conv1d_pair(src, wa, ta, wb, sb, tb, r, d, True, out=dst) is None:
+                        raise RuntimeError("pair kernel declined the benchmark shape")
+            bytes_per_launch = sum(tensor_bytes * (3 if r is not None else 2) for (*_, r, _d) in plan) / len(plan)
+            flop = 2 * 2.0 * 3 * c * c * n * hh * ww
+            name = "conv1d_pair_kernel<64> (fused conv3x1+conv1x3, 64-channel blocks)"
     else:
         hh, ww, c = h // 8, w // 8, 128
         feat = torch.randn(n, hh, ww, c, device=x.device)
@@ -293,20 +308,24 @@ def roofline_infer(model, x, dtype_name):
     avg_s = e0.elapsed_time(e1) * 1e-3 / (reps * inner * len(plan))
     if dtype_name == "bf16":
         achieved = bytes_per_launch / avg_s / 1e9
-        traffic, traffic_file = measured_traffic("conv1d_pair_kernel<64,", n * hh * ww)
+        kernel_key = "nb1d_block64s_kernel" if fused else "conv1d_pair_kernel<64,"
+        traffic, traffic_file = measured_traffic(kernel_key, n * hh * ww)
         per_launch = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                       "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_from_profile": traffic_file,
                       "avg_launch_us": avg_s * 1e6, "launches_per_step": len(plan),
                       "bytes_per_launch": bytes_per_launch, "flop_per_launch": flop, "mfma_tflops": flop / avg_s / 1e12}
-        # The same time priced per BLOCK: a non_bottleneck_1d block needs x in and y out once (2 tensors); its two launches
-        # move 5 (x, mid | mid, x again, y).  achieved = algorithmic block bytes / time of the block's two launches.
-        block_s = 2 * avg_s
+        # The same time priced per BLOCK against the block's algorithmic bytes (x in once, y out once = 2 tensors).  One launch
+        # per block: the same figure.  Two conv1d_pair launches per block move 5 tensors (x, mid | mid, x again, y).
+        launches = 1 if fused else 2
+        block_s = launches * avg_s
         block_alg = 2.0 * tensor_bytes
         per_block = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "achieved": block_alg / block_s / 1e9,
                      "frac": block_alg / block_s / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_block": block_alg,
-                     "launch_bytes_per_block": 5.0 * tensor_bytes, "traffic": None if traffic is None else 2 * traffic,
-                     "avg_block_us": block_s * 1e6, "blocks_per_step": len(plan) // 2,
-                     "what": "64-channel non_bottleneck_1d block = two conv1d_pair launches; model: x read once, y written once"}
+                     "launch_bytes_per_block": (2.0 if fused else 5.0) * tensor_bytes, "launches_per_block": launches,
+                     "traffic": None if traffic is None else launches * traffic,
+                     "avg_block_us": block_s * 1e6, "blocks_per_step": len(plan) // launches,
+                     "mfma_tflops": launches * flop / block_s / 1e12,
+                     "what": "64-channel non_bottleneck_1d block; model: x read once, y written once"}
         return per_launch, per_block
     achieved = flop / avg_s / 1e12
     return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",

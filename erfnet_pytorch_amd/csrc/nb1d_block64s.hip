@@ -21,22 +21,22 @@
 // different rows -- the vertical halo of the two 3x1 convolutions costs nothing, their three taps are simply the three
 // youngest rows of a ring buffer:
 //
-//   step t:  DMA       x row t  requested -> X[t % 8]; it is first read D + 1 = 2 steps later
+//   step t:  DMA       x row t  requested -> X[t % 9]; it is first read D + 1 = 2 steps later
 //            conv3x1_1 a1 row u = t-2-D  from X[u-1], X[u], X[u+1]       -> A1[u % 2]
 //            conv1x3_1 a2 row u = t-3-D  from A1[u % 2]                   -> A2[u % 4]   (zeros for rows outside the image)
 //            conv3x1_2 a3 row u = t-5-D  from A2[u-1], A2[u], A2[u+1]     -> A3[u % 2]
 //            conv1x3_2 y' row u = t-6-D  from A3[u % 2]                   -> Y[u % 2]    (bf16(s4 * acc + t4), staged)
-//            finish    y  row u = t-7-D  = relu(Y[u % 2] + x row u)       -> HBM as whole 16-byte chunks; x is re-read from
-//                                            global memory (an L2 hit: this CU fetched the row eight steps ago), requested one
-//                                            step ahead
-//   one workgroup barrier per step.  The x requests are issued by the four 3x1 waves (2 KB each), the rows are finished by
-//   the four 1x3 waves (16 pixels each): a wave's memory operations complete in order, so a wave that waits for an L2 hit
-//   must not have HBM requests queued in front of it.
+//            finish    y  row u = t-7-D  = relu(Y[u % 2] + X[u % 9])      -> HBM as whole 16-byte chunks (x stays in its ring
+//                                            row until then: x is read from HBM once)
+//   one workgroup barrier per step.  The x requests are issued by the four 3x1 waves (2 KB each), the rows are finished by the
+//   four 1x3 waves (16 pixels each) at the start of their step: the 3x1 waves' matrix instructions start at once and cover that
+//   vector work, the 1x3 waves' matrix instructions then cover the 3x1 waves' epilogues (every wave finishing 8 pixels measured
+//   5 % slower: then all eight delay their matrix instructions together).
 //
 // Every row of every ring has the same layout: 66 pixel slots of 128 bytes (slot = local column + 1; slots 0 and 65 stay
 // zero and only ever feed the frame's outermost columns, which no output column depends on), the eight 16-byte chunks of a
 // pixel XOR-swizzled by the slot index so that a fragment read (16 consecutive pixels, one chunk per quarter wave) is free
-// of bank conflicts.  18 rows = 152 KB of LDS.
+// of bank conflicts.  19 rows = 157 KB of LDS, plus the table of the workgroup's rows.
 //
 // A workgroup's rows are a contiguous run of the linearised (image, strip, row) space (the runs are cut by the host so that
 // every workgroup has about the same number of steps), cut where it crosses into the next strip; each piece ("chunk") of RC output rows takes RC + 4 steps (rows r0-2 .. r0+RC+1 are loaded, a1 / a2 are formed
@@ -58,18 +58,18 @@ namespace nbs {
 constexpr int C = 64, PIXB = 128, KS = 6, CT = 4;
 constexpr int FW = 64, TW = 60;                     // frame / output columns of a strip
 constexpr int ROWB = (FW + 2) * PIXB;               // 8448 bytes per ring row
-constexpr int NX = 8, NA1 = 2, NA2 = 4, NA3 = 2, NY = 2;
+constexpr int NX = 9, NA1 = 2, NA2 = 4, NA3 = 2, NY = 2;
 constexpr int OFF_X = 0;
 constexpr int OFF_A1 = OFF_X + NX * ROWB;
 constexpr int OFF_A2 = OFF_A1 + NA1 * ROWB;
 constexpr int OFF_A3 = OFF_A2 + NA2 * ROWB;
 constexpr int OFF_Y = OFF_A3 + NA3 * ROWB;
 constexpr int OFF_TAB = OFF_Y + NY * ROWB;          // 152064: the slot table, 16 bytes per slot
-constexpr int MAX_SLOTS = 700;
-constexpr int LDS_BYTES = OFF_TAB + MAX_SLOTS * 16; // 163264
+constexpr int MAX_SLOTS = 200;
+constexpr int LDS_BYTES = OFF_TAB + MAX_SLOTS * 16; // 19 rows + the table = 163712
 constexpr int D = 1;                                // steps between the request of an x row and its first use
 constexpr int LAG1 = 2 + D, LAG2 = 3 + D, LAG3 = 5 + D, LAG4 = 6 + D, LAGY = 7 + D;
-static_assert(NX >= 4 + D && (NX & (NX - 1)) == 0, "an x row lives from its request to its last use as a conv3x1_1 tap");
+static_assert(NX == LAGY + 1, "an x row lives from its request to its use as the residual of the finished row");
 constexpr int PAD = 2 * PIXB;                       // the descriptors start two pixels before the tensors (column c0 - 2 of strip 0)
 constexpr int NTHREADS = 512;
 constexpr int FWN = 32, TWN = 28;                   // frame / output columns of a narrow strip
@@ -165,10 +165,9 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
     // this wave's share of a row's memory traffic (3x1 waves: the x request; 1x3 waves: finishing the output): local columns
     // 16 duty .. 16 duty + 15, as two wave-wide accesses of 8 pixels, one 16-byte chunk per lane
     const int duty = 2 * (ROLE >> 1) + half;
-    const int pc = 16 * duty + (lane >> 3);              // + 8 for the second access
+    const int pc = 16 * duty + (lane >> 3);              // + 8 for the second access; (pc + 8 + 1) & 7 is the same
     const int kphys = lane & 7;                           // physical chunk position in the slot; it holds logical chunk klog
-    const int klog = kphys ^ ((pc + 1) & 7);              // (pc + 8 + 1) & 7 is the same
-    const uint32_t gvoff = (uint32_t)(pc * PIXB + klog * 16);     // global offset relative to (row, column c0 - 2); second: + 8 pixels
+    const uint32_t gvoff = (uint32_t)(pc * PIXB + (kphys ^ ((pc + 1) & 7)) * 16);     // global offset relative to (row, column c0 - 2)
     const int lfin = (pc + 1) * PIXB + kphys * 16;        // LDS offset of that chunk inside a ring row; second: + 8 slots
 #pragma unroll
     for (int i = 0; i < NFO; ++i) asm volatile("" : "+v"(fo[i]));
@@ -188,7 +187,7 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
     // the two slots a wave looks at in a step are read one step ahead, so their LDS latency lies under the barrier
     constexpr int LAG_B = VERT ? 0 : LAGY;                            // 3x1 waves: the row to request; 1x3 waves: the row to finish
     i32x4 nxt_me = slot_load(0 - LAG), nxt_b = slot_load(0 - LAG_B);
-    [[maybe_unused]] u32x4 rv[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    int xr = 0;                                                       // t mod NX
 
 #ifdef ERF_DEBUG
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -199,32 +198,31 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
         const Slot me = slot_of(nxt_me), sb = slot_of(nxt_b);
         nxt_me = slot_load(t + 1 - LAG);
         nxt_b = slot_load(t + 1 - LAG_B);
-        // ---- 1x3 waves: finish row t - LAGY (y = relu(y' + x), whole chunks to HBM) with the residual requested a step ago, then
-        //      request the residual of the row finished in the next step: both run under the 3x1 waves' matrix instructions
+        auto xrow = [&](int back) { const int r = xr - back; return OFF_X + (r < 0 ? r + NX : r) * ROWB; };   // ring row of x row t - back
+        // ---- 1x3 waves: finish row t - LAGY: y = relu(y' + x), 16 pixels as whole chunks to HBM; x is still in its ring row.  This
+        //      runs under the 3x1 waves' matrix instructions, which start at once.
         if constexpr (!VERT) {
             if ((sb.fl & 4) && !NBS_DBG(4)) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const i32x4 a = *(const i32x4*)(smem + OFF_Y + ((t - LAGY) & (NY - 1)) * ROWB + lfin + j * 8 * PIXB);
-                    float fa[8], fr[8];
-                    ChunkOps<T>::unpack(a, fa);
-                    ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, rv[j]), fr);
+                    const i32x4 r = *(const i32x4*)(smem + xrow(LAGY) + lfin + j * 8 * PIXB);
+                    float fy[8], fr[8];
+                    ChunkOps<T>::unpack(a, fy);
+                    ChunkOps<T>::unpack(r, fr);
+                    int oo[4];                                         // scalars: bit casts of vector ELEMENTS misread with this compiler
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) fa[e] = fmaxf(fa[e] + fr[e], 0.f);
-                    const i32x4 o = ChunkOps<T>::pack(fa);
+                    for (int e = 0; e < 4; ++e)                        // ReLU on the rounded pairs: same bits as before the rounding
+                        oo[e] = relu_bf16x2(pack_bf16x2(fy[2 * e] + fr[2 * e], fy[2 * e + 1] + fr[2 * e + 1]));
+                    const i32x4 o{oo[0], oo[1], oo[2], oo[3]};
                     const bool ok = pc + 8 * j >= 2 && pc + 8 * j < 2 + sb.tw() && sb.c0 - 2 + pc + 8 * j < p.W;
+                    // non-temporal: the output is not read again by this launch
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y, ok ? gvoff + j * 8 * PIXB : ERF_OOB,
-                                                           (uint32_t)sb.soff, 0);
+                                                           (uint32_t)sb.soff, 2);
                 }
                 // a 16-byte buffer store with a scalar offset reads its data registers for some cycles after its issue, longer when
                 // the memory pipeline is backed up: nothing may rewrite them meanwhile
                 asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-            }
-            const Slot f = slot_of(nxt_b);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool ok = (f.fl & 4) && pc + 8 * j >= 2 && pc + 8 * j < 2 + f.tw() && f.c0 - 2 + pc + 8 * j < p.W;
-                rv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? gvoff + j * 8 * PIXB : ERF_OOB, (uint32_t)f.soff, 0);
             }
         }
         // ---- 3x1 waves: request x row t (always two operations, masked when there is nothing to fetch: the wait below counts them)
@@ -233,7 +231,7 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
             for (int j = 0; j < 2; ++j) {
                 const bool ok = (sb.fl & 8) && pc + 8 * j < sb.fw() && (unsigned)(sb.c0 - 2 + pc + 8 * j) < (unsigned)p.W && !NBS_DBG(8);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rs_x, (__attribute__((address_space(3))) void*)(smem + OFF_X + (t & (NX - 1)) * ROWB + PIXB + (2 * duty + j) * 1024), 16,
+                    rs_x, (__attribute__((address_space(3))) void*)(smem + xrow(0) + PIXB + (2 * duty + j) * 1024), 16,
                     ok ? gvoff + j * 8 * PIXB : ERF_OOB, (uint32_t)sb.soff, 0, 0);
             }
         }
@@ -262,11 +260,9 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
             // fragment addresses of this step
             int fa[6];
             if constexpr (VERT) {
-                const int src = ROLE == 0 ? OFF_X : OFF_A2;
-                const int msk = ROLE == 0 ? NX - 1 : NA2 - 1;
 #pragma unroll
                 for (int tap = 0; tap < 3; ++tap) {
-                    const int rb = src + ((t - LAG - 1 + tap) & msk) * ROWB - shift;
+                    const int rb = (ROLE == 0 ? xrow(LAG + 1 - tap) : OFF_A2 + ((t - LAG - 1 + tap) & (NA2 - 1)) * ROWB) - shift;
 #pragma unroll
                     for (int kc = 0; kc < 2; ++kc) fa[tap * 2 + kc] = fo[kc] + rb;
                 }
@@ -357,18 +353,16 @@ __device__ __forceinline__ void role_loop(const NbStreamParams& p, char* smem, c
             if (me.fl & 16) conv(std::true_type{});
             else conv(std::false_type{});
         }
+        NBS_STAMP(4)
         if constexpr (!VERT) {
-            NBS_STAMP(4)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            NBS_STAMP(5)
-            asm volatile("s_barrier" ::: "memory");
         } else {
-            NBS_STAMP(4)
-            // the x row requested D steps ago has landed (two requests per step, in order)
+            // the x row requested D steps ago has landed (two requests per step, in order, and nothing else in this wave's queue)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * D) : "memory");
-            NBS_STAMP(5)
-            asm volatile("s_barrier" ::: "memory");
         }
+        NBS_STAMP(5)
+        asm volatile("s_barrier" ::: "memory");
+        xr = xr + 1 == NX ? 0 : xr + 1;
         NBS_STAMP(6)
     }
 #ifdef ERF_DEBUG

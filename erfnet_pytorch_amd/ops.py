@@ -299,7 +299,7 @@ def conv1d_pair(x, packed_a, shift_a, packed_b, scale_b, shift_b, residual, dila
 def nb1d_block(x, packed4, table, dilation: int, out=None):
     """A whole non_bottleneck_1d block (eval mode, BatchNorms folded) in one launch.  Returns None when the library does not
     take the shape (the caller then issues the two conv1d_pair launches).  torch.ops.erfnet_mi355.nb1d_block is the same
-    launch as a registered op (it raises instead of returning None)."""
+    launch as a registered op (it issues the two pair launches itself instead of returning None)."""
     n, h, w, c = x.shape
     y = torch.empty_like(x) if out is None else out
     rc = query("erf_nb1d_block_infer", x.data_ptr(), y.data_ptr(), packed4[0].data_ptr(), packed4[1].data_ptr(), packed4[2].data_ptr(),

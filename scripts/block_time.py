@@ -1,7 +1,7 @@
 """Median per-block time of the one-launch block kernel and of the two-pair-launch path.
 usage: block_time.py [channels=64] -- shapes: 64 -> 16x128x256, 16 -> 16x256x512 (the benchmark's maps)."""
-import sys
-sys.path.insert(0, ".")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from erfnet_pytorch_amd import erfnet as E
 from oracle import erfnet_oracle as O

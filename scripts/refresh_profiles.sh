@@ -1,11 +1,11 @@
 #!/bin/bash
-# Regenerates profiles/$ROUND_* (ROUND defaults to r02) on the GPU box: the unprofiled bench line, the rocprofv3 kernel-trace summary of the same
+# Regenerates profiles/$ROUND_* (ROUND defaults to r03) on the GPU box: the unprofiled bench line, the rocprofv3 kernel-trace summary of the same
 # command, the HBM-traffic counters (separate FETCH_SIZE / WRITE_SIZE passes) and the matrix-core utilisation pass.
 # Run from the repository root:  bash scripts/refresh_profiles.sh   (outputs land in gpurun_out/$ROUND/, summaries in profiles/).
 # Through gpurun only gpurun_out/ comes back: afterwards  cp gpurun_out/$ROUND/${ROUND}_* profiles/
 set -eo pipefail
 ROOT=$(pwd)
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT" "$ROOT/profiles"
 timeout -k 10 300 python3 bench.py > "$OUT/bench_line.json"
