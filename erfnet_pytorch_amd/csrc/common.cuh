@@ -51,6 +51,11 @@ typedef __attribute__((ext_vector_type(2))) short i16x2;
 __device__ __forceinline__ int relu_bf16x2(int packed) {
     return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, packed), i16x2{0, 0}));
 }
+// max(packed pair, floor pair) as 16-bit integers: floor 0 is ReLU, floor 0x80008000 (-32768 twice) the identity, so a launch
+// argument can switch the activation without a branch.  Pass SCALARS: a bit cast of a vector element misreads with this compiler.
+__device__ __forceinline__ int max_bf16x2(int packed, int floor_pk) {
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, packed), __builtin_bit_cast(i16x2, floor_pk)));
+}
 __device__ __forceinline__ i32x2 pack_bf16x4(const f32x4& v) {
     i32x2 r;
     r[0] = pack_bf16x2(v[0], v[1]);

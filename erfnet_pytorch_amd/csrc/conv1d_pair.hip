@@ -595,7 +595,7 @@ void conv1d_pair_pc_kernel(const PairParams p) {
         tile_end = (xcd + 1) * per < p.ntiles ? (xcd + 1) * per : p.ntiles;
         G >>= 3;
     }
-    const float floor_v = p.relu ? 0.f : -__builtin_huge_valf();
+    const int floor_pk = p.relu ? 0 : (int)0x80008000;             // max_bf16x2(o, floor_pk): ReLU or identity without a select
 #ifdef ERF_DEBUG
     // diagnostic build only (ERF_PAIR_DBG & 256): shader cycles per section of a stage, summed over this wave's stages,
     // written over the head of y (scripts/pair_pc_phase_time.py reads them)
@@ -656,8 +656,10 @@ void conv1d_pair_pc_kernel(const PairParams p) {
                     for (int c = 0; c < CTW; ++c) {
                         f32x4 v = acc[pt][c];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[c][e] + sh[c][e], 0.f);
-                        *(i32x2*)(smem + moff + mid_w[c] + pt * RS * PIXB) = pack_bf16x4(v);
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[c][e] + sh[c][e];
+                        // ReLU on the rounded pairs (one instruction per two values; the same bits as before the rounding)
+                        const int o0 = relu_bf16x2(pack_bf16x2(v[0], v[1])), o1 = relu_bf16x2(pack_bf16x2(v[2], v[3]));
+                        *(i32x2*)(smem + moff + mid_w[c] + pt * RS * PIXB) = i32x2{o0, o1};
                     }
                 };
                 mfma_phase_shared<C, TC, PTW, CTW>(lb, w, acc, ep1);
@@ -726,23 +728,23 @@ void conv1d_pair_pc_kernel(const PairParams p) {
                     for (int c = 0; c < CTW; ++c) {
                         f32x4 v = acc[pt][c];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = v[e] * sc[c][e] + sh[c][e];
-                            if constexpr (!POST) v[e] = fmaxf(v[e], floor_v);
-                        }
-                        i32x2 o = pack_bf16x4(v);
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[c][e] + sh[c][e];
+                        int o0 = pack_bf16x2(v[0], v[1]), o1 = pack_bf16x2(v[2], v[3]);
                         if constexpr (POST) {          // same rounding points as the staged epilogue: bf16, + residual, bf16
                             f32x4 f, r;
-                            f[0] = __uint_as_float(((uint32_t)o[0]) << 16); f[1] = __uint_as_float(((uint32_t)o[0]) & 0xFFFF0000u);
-                            f[2] = __uint_as_float(((uint32_t)o[1]) << 16); f[3] = __uint_as_float(((uint32_t)o[1]) & 0xFFFF0000u);
+                            f[0] = __uint_as_float(((uint32_t)o0) << 16); f[1] = __uint_as_float(((uint32_t)o0) & 0xFFFF0000u);
+                            f[2] = __uint_as_float(((uint32_t)o1) << 16); f[3] = __uint_as_float(((uint32_t)o1) & 0xFFFF0000u);
                             const i32x2 rr = rv[pt][c];
-                            r[0] = __uint_as_float(((uint32_t)rr[0]) << 16); r[1] = __uint_as_float(((uint32_t)rr[0]) & 0xFFFF0000u);
-                            r[2] = __uint_as_float(((uint32_t)rr[1]) << 16); r[3] = __uint_as_float(((uint32_t)rr[1]) & 0xFFFF0000u);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) f[e] = fmaxf(f[e] + r[e], floor_v);
-                            o = pack_bf16x4(f);
+                            const int r0 = rr[0], r1 = rr[1];
+                            r[0] = __uint_as_float(((uint32_t)r0) << 16); r[1] = __uint_as_float(((uint32_t)r0) & 0xFFFF0000u);
+                            r[2] = __uint_as_float(((uint32_t)r1) << 16); r[3] = __uint_as_float(((uint32_t)r1) & 0xFFFF0000u);
+                            o0 = pack_bf16x2(f[0] + r[0], f[1] + r[1]);
+                            o1 = pack_bf16x2(f[2] + r[2], f[3] + r[3]);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_y, pt < g.ihi ? vo[c] : ERF_OOB,
+                        // the activation on the rounded pairs: one instruction per two values, the same bits as max(v, floor) before the rounding
+                        o0 = max_bf16x2(o0, floor_pk);
+                        o1 = max_bf16x2(o1, floor_pk);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)o0, (uint32_t)o1}, rs_y, pt < g.ihi ? vo[c] : ERF_OOB,
                                                               g.out_soff + pt * rowb, 0);
                     }
                     // the data registers of a buffer store with an SGPR offset must not be rewritten right after its issue
