@@ -573,9 +573,10 @@ def bench_train(args, world, rank, dev, barrier, max_over_ranks):
     model = model.to(dev).train()
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else None
     group = dist.group.WORLD if world > 1 else None
-    # One GPU: the step is replayed from one HIP graph.  Several GPUs: three graphs (forward | backward | Adam) with the loss and
-    # gradient all-reduces issued between the replays -- launched kernel by kernel the step is host-bound (6.5 ms against
-    # 5.4 ms of kernels); --train-graph captures the RCCL all-reduces into one graph instead (verified with a one-rank group only).
+    # One GPU: the step is replayed from one HIP graph.  Several GPUs: five graphs (forward | three backward sections | Adam)
+    # with the loss all-reduce and one gradient bucket's all-reduce issued after each replay -- launched kernel by kernel the
+    # step is host-bound (6.5 ms against 5.4 ms of kernels); --train-graph captures the RCCL all-reduces into one graph
+    # instead (verified with a one-rank group only).
     use_graph = False
     if not getattr(args, "no_graph", False):
         use_graph = True if (world == 1 or getattr(args, "train_graph", False)) else "segments"
