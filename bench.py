@@ -394,25 +394,33 @@ COPY_STREAM = {}     # device index -> the stream host-to-device copies travel o
 
 def run_infer_h2d(args, dev, steps, warmup):
     """The inference pipeline fed from HOST memory, as an evaluation loop is (eval/eval_iou.py:84-93: the loader hands over
-    decoded 8-bit images): every batch travels as uint8 [N,3,H,W] from pinned host memory on a copy stream into one of two
-    device buffers while the previous batch computes (the initial block applies ToTensor()'s / 255 on load), labels and the
-    iouEval histogram as in the headline.  Reported beside the headline, never as `value`."""
+    decoded 8-bit images and label images): every batch travels as uint8 images [N,3,H,W] + uint8 label images [N,1,H,W]
+    (255 = void) from pinned host memory on a copy stream into one of two device buffers while the previous batch computes;
+    the initial block applies ToTensor()'s / 255 on load and the histogram applies Relabel(255, 19) (eval/eval_iou.py:33-37)
+    while counting.  Reported beside the headline, never as `value`."""
     from erfnet_pytorch_amd.iouEval import iouEval
     batch = args.batch or 16
     model = build_model(dev, args.dtype, args.classes)
     g = torch.Generator().manual_seed(99)
     host = [torch.randint(0, 256, (batch, 3, args.height, args.width), generator=g, dtype=torch.uint8).pin_memory() for _ in range(2)]
-    target = torch.randint(0, args.classes, (batch, 1, args.height, args.width), device=dev)
+    void = args.classes - 1                      # the class Relabel maps the void value to (19 of 20 on Cityscapes)
+    host_t = []
+    for _ in range(2):
+        t = torch.randint(0, max(void, 1), (batch, 1, args.height, args.width), generator=g, dtype=torch.uint8)
+        t[torch.rand(t.shape, generator=g) < 0.05] = 255
+        host_t.append(t.pin_memory())
     bufs = [torch.empty_like(h, device=dev) for h in host]
-    ev = iouEval(args.classes)
+    tbufs = [torch.empty_like(h, device=dev) for h in host_t]
+    tbufs[0].copy_(host_t[0])
+    ev = iouEval(args.classes, ignoreIndex=void, relabel=(255, void))
     with torch.no_grad():
-        model.evaluate_batch(bufs[0], target, ev, torch.uint8, ways=args.infer_ways)
+        model.evaluate_batch(bufs[0], tbufs[0], ev, torch.uint8, ways=args.infer_ways)
     torch.cuda.synchronize()
     graphs = []
-    for b in bufs:
+    for b, tb in zip(bufs, tbufs):
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr, capture_error_mode="thread_local"), torch.no_grad():
-            model.evaluate_batch(b, target, ev, torch.uint8, ways=args.infer_ways)
+            model.evaluate_batch(b, tb, ev, torch.uint8, ways=args.infer_ways)
         graphs.append(gr)
     copy_stream = COPY_STREAM.get(dev.index) or torch.cuda.Stream(dev)
     main = torch.cuda.current_stream(dev)
@@ -426,6 +434,7 @@ def run_infer_h2d(args, dev, steps, warmup):
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(consumed[k])          # the batch that last used this buffer has been computed
             bufs[k].copy_(host[k], non_blocking=True)
+            tbufs[k].copy_(host_t[k], non_blocking=True)
             copied[k].record(copy_stream)
         if i > 0:                                        # compute the batch copied one step earlier
             j = (i - 1) & 1
@@ -441,11 +450,12 @@ def run_infer_h2d(args, dev, steps, warmup):
         step(i)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    nbytes = host[0].numel()
+    nbytes = host[0].numel() + host_t[0].numel()
     return {"value": batch * steps / elapsed, "unit": "img/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
             "dtype": args.dtype, "h2d_bytes_per_step": nbytes, "h2d_gbs": nbytes * steps / elapsed / 1e9,
-            "config": {"workload": f"as the headline, each batch copied from pinned host memory as uint8 [N,3,{args.height},{args.width}] "
-                                   "on a copy stream, double-buffered; / 255 applied by the initial block on load",
+            "config": {"workload": f"as the headline, each batch copied from pinned host memory as uint8 images [N,3,{args.height},{args.width}] "
+                                   "+ uint8 label images (255 = void) on a copy stream, double-buffered; / 255 applied by the initial "
+                                   "block on load, Relabel(255, void class) by the histogram while counting",
                        "hip_graph": True, "streams": max(1, min(args.infer_ways, batch))}}
 
 

@@ -84,6 +84,8 @@ SIGNATURES = {
     "erf_nhwc_to_nchw": (I, [P, I, P, I, I, I, I, I, P]),
     "erf_argmax_c": (I, [P, I, P, I, I, I, LL, P]),
     "erf_iou_hist_accumulate": (I, [P, I, P, I, LL, I, P, P]),
+    "erf_iou_hist_accumulate_relabel": (I, [P, I, P, I, LL, I, I, I, P, P]),
+    "erf_labels_from_u8": (I, [P, P, LL, I, I, P]),
     "erf_iou_planes_workspace_bytes": (c_size_t, [I]),
     "erf_iou_planes_accumulate": (I, [P, I, P, I, I, I, LL, I, P, P, P]),
     # ---- training

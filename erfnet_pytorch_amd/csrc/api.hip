@@ -362,7 +362,19 @@ int erf_argmax_c(const void* logits, int dtype, void* labels, int label_bytes, i
 int erf_iou_hist_accumulate(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count, int nc,
                             long long* hist, void* stream) {
     if (!pred || !label || !hist) return ERF_EINVAL;
-    return iou_hist_launch(pred, pred_bytes, label, label_bytes, count, nc, hist, (hipStream_t)stream);
+    return iou_hist_launch(pred, pred_bytes, label, label_bytes, count, nc, -1, 0, hist, (hipStream_t)stream);
+}
+
+int erf_iou_hist_accumulate_relabel(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count, int nc,
+                                    int olabel, int nlabel, long long* hist, void* stream) {
+    if (!pred || !label || !hist || olabel < 0) return ERF_EINVAL;
+    return iou_hist_launch(pred, pred_bytes, label, label_bytes, count, nc, olabel, nlabel, hist, (hipStream_t)stream);
+}
+
+int erf_labels_from_u8(const void* src, long long* dst, long long count, int olabel, int nlabel, void* stream) {
+    if (!src || !dst || count < 0) return ERF_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return ERF_EINVAL;
+    return labels_from_u8_launch(src, dst, count, olabel, nlabel, (hipStream_t)stream);
 }
 
 size_t erf_iou_planes_workspace_bytes(int nc) { return iou_planes_workspace_bytes(nc); }

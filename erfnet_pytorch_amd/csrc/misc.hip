@@ -255,11 +255,44 @@ int argmax_launch(const void* z, int dtype, void* lab, int label_bytes, int N, i
 }
 
 // ------------------------------------------------------------------------------------------
+// ToLabel() + Relabel(olabel, nlabel) of the loaders (train/transform.py:53-68): 8-bit label maps as decoded from the
+// label images -> int64 class indices, with one value mapped to another.  16 labels per thread and trip.
+__global__ __launch_bounds__(256) void labels_from_u8_kernel(const unsigned char* __restrict__ src, long long* __restrict__ dst,
+                                                             long long count, int olabel, int nlabel) {
+    const long long groups = count >> 4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        const i32x4 v = *(const i32x4*)(src + g * 16);
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            int a = (v[k >> 2] >> (8 * (k & 3))) & 255, b = (v[k >> 2] >> (8 * (k & 3) + 8)) & 255;
+            a = a == olabel ? nlabel : a;
+            b = b == olabel ? nlabel : b;
+            *(i32x4*)(dst + g * 16 + k) = i32x4{a, 0, b, 0};
+        }
+    }
+    for (long long i = groups * 16 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const int a = src[i];
+        dst[i] = a == olabel ? nlabel : a;
+    }
+}
+
+int labels_from_u8_launch(const void* src, long long* dst, long long count, int olabel, int nlabel, hipStream_t stream) {
+    if (count == 0) return ERF_OK;
+    long long blocks = (count / 16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(labels_from_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const unsigned char*)src, dst, count, olabel, nlabel);
+    return erf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
 // Confusion-matrix histogram: per-workgroup nc x nc counters in LDS (atomics), flushed with one
 // global 64-bit atomic per non-zero cell.  Grid-stride, 8 pixels per thread per trip.
 template <typename TP, typename TLB>
 __global__ __launch_bounds__(1024) void iou_hist_kernel(const TP* __restrict__ pred, const TLB* __restrict__ label,
-                                                       long long count, int nc, unsigned long long* __restrict__ hist) {
+                                                       long long count, int nc, int olabel, unsigned nlabel,
+                                                       unsigned long long* __restrict__ hist) {
     // one private copy of the counters per wave (less contention on the LDS atomics); a thread takes 8 consecutive
     // pixels per trip (vector loads) and merges runs of equal (label, prediction) pairs before touching LDS --
     // label maps are piecewise constant, so most trips end in one or two atomics
@@ -289,7 +322,8 @@ __global__ __launch_bounds__(1024) void iou_hist_kernel(const TP* __restrict__ p
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const unsigned long long g = (unsigned long long)(long long)lv[k], q = (unsigned long long)(long long)pv[k];
-            const unsigned glo = (unsigned)g, qlo = (unsigned)q;
+            const bool re = olabel >= 0 && (long long)g == (long long)olabel;               // Relabel(olabel, nlabel) on the target
+            const unsigned glo = re ? nlabel : (unsigned)g, qlo = (unsigned)q;
             const bool ok = (unsigned)(g >> 32) == 0u && (unsigned)(q >> 32) == 0u && glo < (unsigned)nc && qlo < (unsigned)nc;
             key[k] = ok ? (int)(glo * (unsigned)nc + qlo) : nc * nc;
         }
@@ -303,7 +337,9 @@ __global__ __launch_bounds__(1024) void iou_hist_kernel(const TP* __restrict__ p
     }
     // tail (count not a multiple of 8)
     for (long long i = groups * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const long long g = (long long)label[i], q = (long long)pred[i];
+        long long g = (long long)label[i];
+        const long long q = (long long)pred[i];
+        if (olabel >= 0 && g == olabel) g = nlabel;
         atomicAdd(&mine[(g >= 0 && g < nc && q >= 0 && q < nc) ? (int)(g * nc + q) : nc * nc], 1u);
     }
     __syncthreads();
@@ -314,15 +350,16 @@ __global__ __launch_bounds__(1024) void iou_hist_kernel(const TP* __restrict__ p
 }
 
 int iou_hist_launch(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count, int nc,
-                    long long* hist, hipStream_t stream) {
+                    int olabel, int nlabel, long long* hist, hipStream_t stream) {
     if (nc < 1 || nc > 32 || count < 0) return ERF_EINVAL;
+    if (olabel >= 0 && (nlabel < 0 || nlabel >= nc)) return ERF_EINVAL;          // olabel < 0: no relabelling
     if (count == 0) return ERF_OK;
     // One workgroup of 16 waves per CU at most: every workgroup ends with one 64-bit global atomic per non-zero cell, and
     // atomics on one address are served one after the other -- 1024 small workgroups spent most of the launch there.
     long long blocks = (count + 1024 * 8 * 4 - 1) / (1024 * 8 * 4);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-#define IH(TP, TLB) hipLaunchKernelGGL((iou_hist_kernel<TP, TLB>), dim3((unsigned)blocks), dim3(1024), 0, stream, (const TP*)pred, (const TLB*)label, count, nc, (unsigned long long*)hist)
+#define IH(TP, TLB) hipLaunchKernelGGL((iou_hist_kernel<TP, TLB>), dim3((unsigned)blocks), dim3(1024), 0, stream, (const TP*)pred, (const TLB*)label, count, nc, olabel, (unsigned)nlabel, (unsigned long long*)hist)
     if (pred_bytes == 1 && label_bytes == 8) IH(unsigned char, long long);
     else if (pred_bytes == 8 && label_bytes == 8) IH(long long, long long);
     else if (pred_bytes == 1 && label_bytes == 1) IH(unsigned char, unsigned char);

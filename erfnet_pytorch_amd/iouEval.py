@@ -24,8 +24,13 @@ from . import ops
 
 class iouEval:
 
-    def __init__(self, nClasses, ignoreIndex=19):
+    def __init__(self, nClasses, ignoreIndex=19, relabel=None):
+        """relabel = (olabel, nlabel): label-map targets are counted as after Relabel(olabel, nlabel) (eval/eval_iou.py:37:
+        (255, 19)), so the raw 8-bit label images can be handed to addBatch; predictions are never relabelled."""
         self.nClasses = nClasses
+        self.relabel = None if relabel is None else (int(relabel[0]), int(relabel[1]))
+        if self.relabel is not None and not (0 <= self.relabel[0] and 0 <= self.relabel[1] < nClasses):
+            raise ValueError(f"iouEval: relabel {relabel} must map a non-negative value to a class below {nClasses}")
         # an ignoreIndex >= nClasses means "no ignore class" (train/iouEval.py:12)
         self.ignoreIndex = ignoreIndex if nClasses > ignoreIndex else -1
         if nClasses > 32:
@@ -47,7 +52,7 @@ class iouEval:
         if x.dim() == 4 and x.size(1) != 1 or y.dim() == 4 and y.size(1) != 1:
             return self._add_planes(x, y, dev)
         self.reserve(dev)
-        ops.iou_hist_accumulate(x, y, self.nClasses, self._hist)
+        ops.iou_hist_accumulate(x, y, self.nClasses, self._hist, self.relabel)
 
     def reserve(self, dev):
         """Allocates (and clears) the device counters for label-map inputs on the current stream.  addBatch does this by

@@ -373,7 +373,15 @@ def argmax_c(logits: torch.Tensor, label_dtype=torch.int64) -> torch.Tensor:
     return T.argmax_c(logits.contiguous(), 1 if label_dtype == torch.uint8 else 8)
 
 
-def iou_hist_accumulate(pred: torch.Tensor, label: torch.Tensor, nc: int, hist: torch.Tensor):
-    """hist (int64 [nc*nc+1], device) += confusion counts of (label, pred)."""
-    T.iou_hist_accumulate(pred.contiguous(), label.contiguous(), nc, hist)
+def iou_hist_accumulate(pred: torch.Tensor, label: torch.Tensor, nc: int, hist: torch.Tensor, relabel=None):
+    """hist (int64 [nc*nc+1], device) += confusion counts of (label, pred); relabel = (olabel, nlabel): label values equal to
+    olabel count as nlabel."""
+    olabel, nlabel = (-1, 0) if relabel is None else relabel
+    T.iou_hist_accumulate(pred.contiguous(), label.contiguous(), nc, hist, int(olabel), int(nlabel))
     return hist
+
+
+def labels_from_u8(t: torch.Tensor, relabel=None) -> torch.Tensor:
+    """uint8 label maps -> int64 targets, relabel = (olabel, nlabel) applied on the way (ToLabel() + Relabel of the loaders)."""
+    olabel, nlabel = (-1, 0) if relabel is None else relabel
+    return T.labels_from_u8(t.contiguous(), int(olabel), int(nlabel))

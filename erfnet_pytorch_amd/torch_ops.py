@@ -429,8 +429,9 @@ _register("argmax_c(Tensor logits, int label_bytes) -> Tensor", _argmax_c,
           lambda logits, label_bytes: logits.new_empty((logits.shape[0], logits.shape[2], logits.shape[3]), dtype=_label_dtype(label_bytes)))
 
 
-def _iou_hist_accumulate(pred, label, nc, hist):
-    """hist (int64 [nc*nc+1]) += confusion counts of (label, pred); eval/iouEval.py:18-60 as a histogram."""
+def _iou_hist_accumulate(pred, label, nc, hist, olabel=-1, nlabel=0):
+    """hist (int64 [nc*nc+1]) += confusion counts of (label, pred); eval/iouEval.py:18-60 as a histogram.
+    olabel >= 0: counted as after Relabel(olabel, nlabel) on the label map (eval/eval_iou.py:37)."""
     if pred.numel() != label.numel():
         raise ValueError("prediction and label maps differ in size")
     for t in (pred, label):
@@ -438,12 +439,30 @@ def _iou_hist_accumulate(pred, label, nc, hist):
             raise TypeError("label maps must be contiguous uint8 or int64 tensors")
     if hist.dtype != torch.int64 or hist.numel() < nc * nc + 1:
         raise ValueError("hist: int64 [nc*nc+1]")
-    call("erf_iou_hist_accumulate", pred.data_ptr(), pred.element_size(), label.data_ptr(), label.element_size(),
-         pred.numel(), nc, hist.data_ptr(), _stream())
+    if olabel >= 0:
+        call("erf_iou_hist_accumulate_relabel", pred.data_ptr(), pred.element_size(), label.data_ptr(), label.element_size(),
+             pred.numel(), nc, int(olabel), int(nlabel), hist.data_ptr(), _stream())
+    else:
+        call("erf_iou_hist_accumulate", pred.data_ptr(), pred.element_size(), label.data_ptr(), label.element_size(),
+             pred.numel(), nc, hist.data_ptr(), _stream())
 
 
-_register("iou_hist_accumulate(Tensor pred, Tensor label, int nc, Tensor(a!) hist) -> ()", _iou_hist_accumulate,
-          lambda pred, label, nc, hist: None)
+_register("iou_hist_accumulate(Tensor pred, Tensor label, int nc, Tensor(a!) hist, int olabel=-1, int nlabel=0) -> ()",
+          _iou_hist_accumulate, lambda pred, label, nc, hist, olabel=-1, nlabel=0: None)
+
+
+def _labels_from_u8(src, olabel, nlabel):
+    """ToLabel() + Relabel(olabel, nlabel) (train/transform.py:53-68): uint8 label maps -> int64, one value mapped to another
+    (olabel < 0: conversion only)."""
+    if src.dtype != torch.uint8 or not src.is_contiguous():
+        raise TypeError("labels_from_u8: a contiguous uint8 tensor")
+    dst = torch.empty(src.shape, dtype=torch.int64, device=src.device)
+    call("erf_labels_from_u8", src.data_ptr(), dst.data_ptr(), src.numel(), int(olabel), int(nlabel), _stream())
+    return dst
+
+
+_register("labels_from_u8(Tensor src, int olabel, int nlabel) -> Tensor", _labels_from_u8,
+          lambda src, olabel, nlabel: src.new_empty(src.shape, dtype=torch.int64))
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

@@ -98,8 +98,11 @@ class _NoCollection:
 class Trainer:
     def __init__(self, model: E.ERFNet, class_weights=None, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
                  group=None, world_size=1, overlap=True, only_encode=False, fused_head_loss=True, force_collectives=False,
-                 graph=False):
-        """`only_encode`: the first stage of the reference's recipe (train/main.py:495 `train(args, model, True)`,
+                 graph=False, relabel=None):
+        """`relabel` = (olabel, nlabel): uint8 targets (the decoded label images) become int64 class indices on the device
+        with olabel mapped to nlabel -- ToLabel() + Relabel of the loaders (train/main.py:65-66, train/transform.py:53-68);
+        without it uint8 targets are converted only.
+        `only_encode`: the first stage of the reference's recipe (train/main.py:495 `train(args, model, True)`,
         :203 `model(inputs, only_encode=enc)`): logits from Encoder.output_conv at 1/8 resolution against targets of
         that size; the decoder's parameters take no part and are left untouched.
         `force_collectives`: issue the loss and gradient-bucket all-reduces even when world_size is 1 (a one-rank process
@@ -115,6 +118,7 @@ class Trainer:
         any) alias a static buffer the next step overwrites.  Everything that changes from step to step lives on the device for this (dropout seed counter,
         Adam's step count and learning rate), graph or not, so both ways of running give the same bits."""
         self.model = model
+        self.relabel = None if relabel is None else (int(relabel[0]), int(relabel[1]))
         self.only_encode = only_encode
         # Decoder.output_conv + loss in one pass each way (the logits stay in registers); step() then returns
         # (loss, None).  Set False to get the logits back, e.g. for an IoU over the training batches.
@@ -253,10 +257,13 @@ class Trainer:
 
     def step(self, images, targets):
         """images [N,3,H,W] (fp32 / bf16, or uint8 [N,3,H,W] / [N,H,W,3]: ToTensor()'s / 255 is then applied by the initial
-        block); targets [N,1,H,W] or [N,H,W] int64.  Returns (global loss tensor, logits or None).  In graph modes the loss is a
+        block); targets [N,1,H,W] or [N,H,W] int64, or uint8 (see `relabel`).  Returns (global loss tensor, logits or None).  In graph modes the loss is a
         copy; returned logits alias a static buffer that the next step overwrites (clone them to keep them)."""
         if targets.dim() == 4:
             targets = targets[:, 0]                                   # criterion(outputs, targets[:, 0]), train/main.py:202
+        if targets.dtype == torch.uint8:
+            from . import ops
+            targets = ops.labels_from_u8(targets, self.relabel)
         self._sync_lr()
         if not self.use_graph or self._host_masks():
             return self._step_eager(images, targets)

@@ -146,6 +146,15 @@ int erf_nhwc_to_nchw(const void* src, int src_dtype, void* dst, int dst_dtype, i
 int erf_argmax_c(const void* logits, int dtype, void* labels, int label_bytes, int N, int C, long long HW, void* stream);
 int erf_iou_hist_accumulate(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count,
                             int nc, long long* hist, void* stream);
+/* The label side of the loaders' target transform on the device (eval/eval_iou.py:33-37 ToLabel(), Relabel(255, 19);
+ * train/main.py:65-66; train/transform.py:53-68), so that a loader can hand over the decoded 8-bit label images:
+ * erf_iou_hist_accumulate_relabel counts as erf_iou_hist_accumulate does after `label[label == olabel] = nlabel`
+ *   (0 <= olabel, 0 <= nlabel < nc), without writing the relabelled map;
+ * erf_labels_from_u8 writes dst[i] = (src[i] == olabel ? nlabel : src[i]) as int64 -- ToLabel().long() + Relabel in one pass,
+ *   the targets of the loss (olabel < 0: conversion only).  src and dst 16-byte aligned. */
+int erf_iou_hist_accumulate_relabel(const void* pred, int pred_bytes, const void* label, int label_bytes, long long count,
+                                    int nc, int olabel, int nlabel, long long* hist, void* stream);
+int erf_labels_from_u8(const void* src, long long* dst, long long count, int olabel, int nlabel, void* stream);
 /* iouEval.addBatch when an input already has nClasses planes (train/iouEval.py:32-46 `else: x_onehot = x.float()`): the
  * reference then multiplies the planes as they are (one-hot or soft scores), :60-65.  sums [3][classes] fp64 (tp, fp, fn;
  * classes = ignore_index when ignore_index >= 0, else nc) is ADDED to:

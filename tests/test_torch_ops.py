@@ -44,6 +44,7 @@ def _samples(dev, dtype=torch.bfloat16):
         "weighted_ce_bwd": ((logits, target, None, f(1)), [((2, 20, 16, 32), torch.float32)]),
         "argmax_c": ((logits, 8), [((2, 16, 32), torch.int64)]),
         "iou_hist_accumulate": ((t(2, 16, 32, dt=torch.uint8), target, 20, t(401, dt=torch.int64)), []),
+        "labels_from_u8": ((t(2, 16, 32, dt=torch.uint8), 255, 19), [((2, 16, 32), torch.int64)]),
         "adam_fused_arena_": ((f(100), f(100), f(100), f(100), 5e-4, 0.9, 0.999, 1e-8, 1e-4, 3, 1.0), []),
     }
 

@@ -47,7 +47,7 @@ def test_single_gpu_line_has_every_leg():
     assert abs(rf["frac_of_measured"] - rf["achieved"] / mp["hbm_copy_gbs"]) < 1e-9 and "frac_of_measured" in rb
     assert abs(d["mfma_frac"] - d["model_tflops"] / 2500.0) < 1e-9 and d["mfma_frac_of_measured"] > d["mfma_frac"]
     h2d = d["inference_with_h2d"]
-    assert h2d["value"] > 0 and h2d["h2d_bytes_per_step"] == 2 * 3 * 64 * 128 and "uint8" in h2d["config"]["workload"]
+    assert h2d["value"] > 0 and h2d["h2d_bytes_per_step"] == 2 * 4 * 64 * 128 and "uint8" in h2d["config"]["workload"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     tr = d["training"]
