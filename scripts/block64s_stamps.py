@@ -5,11 +5,10 @@ sys.path.insert(0, ".")
 import numpy as np
 import torch
 from erfnet_pytorch_amd import erfnet as E, _lib
-from oracle import erfnet_oracle as O
+from erfnet_pytorch_amd import synthetic as S
 dev = torch.device("cuda:0")
 blk = E.non_bottleneck_1d(64, 0.03, 1)
-sd = O.synthetic_state(O.nb_template("encoder.layers.1", 64))
-blk.load_state_dict({k[len("encoder.layers.1."):]: v for k, v in sd.items()})
+S.load_synthetic(blk)
 blk = blk.to(dev).eval()
 E.FUSE_BLOCKS = (16, 64)
 x = torch.relu(torch.randn(16, 128, 256, 64, device=dev)).to(torch.bfloat16)

@@ -4,13 +4,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from erfnet_pytorch_amd import erfnet as E
-from oracle import erfnet_oracle as O
+from erfnet_pytorch_amd import synthetic as S
 dev = torch.device("cuda:0")
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hw = (128, 256) if c == 64 else (256, 512)
 blk = E.non_bottleneck_1d(c, 0.03, 1)
-sd = O.synthetic_state(O.nb_template("encoder.layers.1", c))
-blk.load_state_dict({k[len("encoder.layers.1."):]: v for k, v in sd.items()})
+S.load_synthetic(blk)
 blk = blk.to(dev).eval()
 E.FUSE_BLOCKS = (16, 64)
 x = torch.relu(torch.randn(16, *hw, c, device=dev)).to(torch.bfloat16)

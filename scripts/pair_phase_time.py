@@ -4,14 +4,13 @@ import os, sys
 sys.path.insert(0, ".")
 import torch
 from erfnet_pytorch_amd import erfnet as E, ops
-from oracle import erfnet_oracle as O
+from erfnet_pytorch_amd import synthetic as S
 dev = torch.device("cuda:0")
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 hw = {128: (64, 128), 64: (128, 256), 16: (256, 512)}[c]
 blk = E.non_bottleneck_1d(c, 0.03, d)
-sd = O.synthetic_state(O.nb_template("encoder.layers.1", c))
-blk.load_state_dict({k[len("encoder.layers.1."):]: v for k, v in sd.items()})
+S.load_synthetic(blk)
 blk = blk.to(dev).eval()
 k = blk._cached(1)
 x = torch.relu(torch.randn(16, *hw, c, device=dev)).to(torch.bfloat16)
