@@ -662,6 +662,8 @@ def main():
         # auto, several GPUs: the data-parallel training step is the headline (the leg with an exchange step); the inference
         # pipeline (independent shards) is reported beside it
         res = run_train(args, world, rank, dev, batch=args.train_batch)
+        res["config"]["one_gpu_counterpart"] = ("`training.value` of the `--gpus 1` line (same step, same per-GPU batch); that line's own "
+                                                 "`value` is the inference leg, which is not what this `value` scales from")
         free_gpu()
         res["inference"] = leg(run_infer(args, world, rank, dev, steps=args.infer_steps, warmup=args.infer_warmup, roofline=False))
     res.setdefault("world_size", world)
