@@ -64,6 +64,7 @@ SIGNATURES = {
     "erf_conv1d_dgrad_bias_partial": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P, P]),
     "erf_channel_sum_finalize_many": (I, [P, I, P]),
     "erf_conv1d_dgrad_bn_backward": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P, P, P, P]),
+    "erf_conv1d_dgrad_bn_backward_bits": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P, P, P, P, P, I, P, P, P, P, P]),
     "erf_conv1d_pack_many": (I, [P, I, I, I, P]),
     "erf_conv1d_pair": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "erf_nb1d_block_infer": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "erf_bn_workspace_bytes": (c_size_t, [I]),
     "erf_bn_stats_finalize": (I, [P, I, LL, I, P, P, P, P, F, F, P, P, P, P, P, P]),
     "erf_bn_apply": (I, [P, P, P, P, P, P, P, I, I, LL, I, I, P]),
+    "erf_bn_apply_gates": (I, [P, P, P, P, P, P, P, I, I, LL, I, I, P, P]),
     "erf_bn_backward": (I, [P, P, P, P, P, P, P, I, P, P, P, P, I, I, LL, I, P, P]),
     "erf_relu_backward": (I, [P, P, P, I, LL, P]),
     "erf_channel_sum": (I, [P, I, LL, I, P, P, P]),

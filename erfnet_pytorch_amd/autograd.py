@@ -176,11 +176,12 @@ _HANDOFF = threading.local()             # one slot per backward thread (autogra
 
 
 class BnTail:
-    __slots__ = ("mod", "prefix", "out_ptr", "z", "mean", "invstd", "gamma", "mask", "training")
+    __slots__ = ("mod", "prefix", "out_ptr", "z", "mean", "invstd", "gamma", "mask", "training", "gate_bits")
 
-    def __init__(self, mod, prefix, out, z, mean, invstd, gamma, mask, training):
+    def __init__(self, mod, prefix, out, z, mean, invstd, gamma, mask, training, gate_bits=None):
         self.mod, self.prefix, self.out_ptr = mod, prefix, out.data_ptr()
         self.z, self.mean, self.invstd, self.gamma, self.mask, self.training = z, mean, invstd, gamma, mask, training
+        self.gate_bits = gate_bits            # ReLU gate of `out`, one byte per 16-byte chunk (bn_apply_gates), or None
 
 
 def _with_tail(out, tail):
@@ -205,18 +206,28 @@ def _take_handoff(g):
 
 
 def conv1d_dgrad_bn_backward(dy, packed_t, gate, residual, axis, dilation, z, mean, invstd, gamma, mask, batch_stats,
-                             dgamma=None, dbeta=None):
+                             dgamma=None, dbeta=None, gate_bits=None):
     """dx = [gate > 0] * (conv1d_dgrad(dy) + residual), then the backward of the BatchNorm (z, mean, invstd, gamma, mask)
-    whose output gradient dx is.  Returns (dx, dz, dgamma, dbeta), or None when the fused kernel does not take the shape."""
+    whose output gradient dx is.  Returns (dx, dz, dgamma, dbeta), or None when the fused kernel does not take the shape.
+    gate_bits: the gate as bn_apply_gates wrote it (read in place of the tensor when the kernel takes that form)."""
     n, h, w, c = dy.shape
     dev = dy.device
     dx, dz = torch.empty_like(dy), torch.empty_like(z)
     dgamma = torch.empty(c, device=dev) if dgamma is None else dgamma
     dbeta = torch.empty(c, device=dev) if dbeta is None else dbeta
     ws = _ws(size_query("erf_bn_workspace_bytes", c), dev)
-    rc = query("erf_conv1d_dgrad_bn_backward", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), gate.data_ptr(), _p(residual),
-               ops.dt(dy), n, h, w, c, axis, dilation, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-               _p(mask), int(batch_stats), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream())
+    rc = -2
+    if gate_bits is not None and GATE_BITS:
+        rc = query("erf_conv1d_dgrad_bn_backward_bits", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), gate_bits.data_ptr(),
+                   _p(residual), ops.dt(dy), n, h, w, c, axis, dilation, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                   gamma.data_ptr(), _p(mask), int(batch_stats), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                   _stream())
+        if rc == 0:
+            GATE_BITS_CALLS[0] += 1
+    if rc == -2:
+        rc = query("erf_conv1d_dgrad_bn_backward", dy.data_ptr(), dx.data_ptr(), packed_t.data_ptr(), gate.data_ptr(), _p(residual),
+                   ops.dt(dy), n, h, w, c, axis, dilation, z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                   _p(mask), int(batch_stats), dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream())
     if rc == 0:
         FUSED_BN_BACKWARD_CALLS[0] += 1
         return dx, dz, dgamma, dbeta
@@ -228,6 +239,28 @@ def conv1d_dgrad_bn_backward(dy, packed_t, gate, residual, axis, dilation, z, me
 def bn_apply(z, center, scale, shift, residual=None, mask=None, relu=True):
     """y = act(((z - center) * scale + shift) * mask + residual)"""
     return ops.T.bn_apply(z, center, scale, shift, residual, mask, relu)
+
+
+# The ReLU gate of a BatchNorm-apply output as one byte per 16-byte chunk (bit e = [value e > 0]), written by the pass that
+# produces the tensor: the data-gradient launch that applies that ReLU's backward reads the bytes instead of the tensor.
+GATE_BITS = True                         # module switch for tests; the environment is never consulted
+GATE_BITS_CALLS = [0]                    # diagnostic counter: fused launches that read a gate as bytes
+
+
+def bn_apply_gates(z, center, scale, shift, residual=None, mask=None):
+    """(y, gate bytes) with y = relu(((z - center) * scale + shift) * mask + residual); gate bytes None when switched off or the
+    kernel declines the shape (then y comes from bn_apply)."""
+    if GATE_BITS and z.dtype == torch.bfloat16:
+        n, h, w, c = z.shape
+        y = torch.empty_like(z)
+        bits = torch.empty(z.numel() * z.element_size() // 16, dtype=torch.uint8, device=z.device)
+        rc = query("erf_bn_apply_gates", z.data_ptr(), y.data_ptr(), _p(center), scale.data_ptr(), shift.data_ptr(), _p(residual),
+                   _p(mask), ops.dt(z), n, h * w, c, 1, bits.data_ptr(), _stream())
+        if rc == 0:
+            return y, bits
+        if rc != -2:
+            raise RuntimeError(f"erf_bn_apply_gates failed with status {rc}")
+    return bn_apply(z, center, scale, shift, residual, mask, True), None
 
 
 def bn_backward(g, gate, mask, z, mean, invstd, gamma, batch_stats, want_g_out=False, dgamma=None, dbeta=None):
@@ -441,18 +474,19 @@ class _NB1dFn(torch.autograd.Function):
         a1 = ops.conv1d(xh, ops.packed_conv1d(mod, "conv3x1_1", w1, code), None, _f32(b1), None, AXIS_H, 1, True)
         z2, mean1, invstd1, s1, t1 = conv1d_bn_stats(a1, ops.packed_conv1d(mod, "conv1x3_1", w2, code), _f32(b2), AXIS_W, 1,
                                                      mod.bn1, training)
-        a2 = bn_apply(z2, mean1, s1, t1)
+        a2, a2_bits = bn_apply_gates(z2, mean1, s1, t1)
         a3 = ops.conv1d(a2, ops.packed_conv1d(mod, "conv3x1_2", w3, code), None, _f32(b3), None, AXIS_H, d, True)
         z4, mean2, invstd2, s2, t2 = conv1d_bn_stats(a3, ops.packed_conv1d(mod, "conv1x3_2", w4, code), _f32(b4), AXIS_W, d,
                                                      mod.bn2, training)
         mask = None
         if training and mod.dropout.p != 0:
             mask = dropout_mask(xh.shape[0], xh.shape[3], mod.dropout.p, xh.device, mod.__dict__.get("_erf_forced_mask"), mod)
-        out = bn_apply(z4, mean2, s2, t2, residual=xh, mask=mask)
+        out, out_bits = bn_apply_gates(z4, mean2, s2, t2, residual=xh, mask=mask)
         ctx.save_for_backward(xh, a1, z2, a2, a3, z4, out, mean1, invstd1, mean2, invstd2, w1, w2, w3, w4, g1, g2)
         ctx.mask, ctx.d, ctx.training, ctx.mod = mask, d, training, mod
+        ctx.a2_bits = a2_bits
         ctx.tail = _tail_of(x, xh)
-        return _with_tail(out, BnTail(mod, "bn2", out, z4, mean2, invstd2, g2, mask, training))
+        return _with_tail(out, BnTail(mod, "bn2", out, z4, mean2, invstd2, g2, mask, training, out_bits))
 
     @staticmethod
     def backward(ctx, gout):
@@ -475,7 +509,7 @@ class _NB1dFn(torch.autograd.Function):
                                      o("conv3x1_2.bias", (c,)), defer=True)
         fused = conv1d_dgrad_bn_backward(dz3, ops.packed_conv1d(ctx.mod, "conv3x1_2", w3, code, 1), a2, None, AXIS_H, d, z2,
                                          mean1, invstd1, _f32(g1), None, ctx.training, o("bn1.weight", (c,)),
-                                         o("bn1.bias", (c,))) if FUSE_BN_BACKWARD else None
+                                         o("bn1.bias", (c,)), gate_bits=ctx.a2_bits) if FUSE_BN_BACKWARD else None
         if fused is not None:
             _, dz2, dg1, dbe1 = fused
         else:
@@ -490,7 +524,8 @@ class _NB1dFn(torch.autograd.Function):
             psk = _Sink(t.mod, claim=False)
             fused = conv1d_dgrad_bn_backward(dz1, ops.packed_conv1d(ctx.mod, "conv3x1_1", w1, code, 1), xh, g_res, AXIS_H, 1, t.z,
                                              t.mean, t.invstd, _f32(t.gamma), t.mask, t.training,
-                                             psk.out(t.prefix + ".weight", (c,), dev), psk.out(t.prefix + ".bias", (c,), dev))
+                                             psk.out(t.prefix + ".weight", (c,), dev), psk.out(t.prefix + ".bias", (c,), dev),
+                                             gate_bits=t.gate_bits)
         if fused is not None:
             dx = fused[0]
             _HANDOFF.slot = (dx.data_ptr(), tuple(dx.shape), fused[1:])

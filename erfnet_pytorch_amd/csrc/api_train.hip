@@ -58,6 +58,15 @@ int erf_bn_apply(const void* z, void* y, const float* center, const float* scale
     return bn_apply_launch(z, y, center, scale, shift, residual, mask, dtype, (long long)N * HW, C, HW, relu, (hipStream_t)stream);
 }
 
+// erf_bn_apply that also writes the ReLU gate of its output as one byte per 16-byte chunk (bit e = [y value e > 0]; bf16: 8
+// channels per byte, fp32: 4), for the data-gradient launches that would otherwise read y back for its signs only
+int erf_bn_apply_gates(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* residual,
+                       const float* mask, int dtype, int N, long long HW, int C, int relu, void* gate_out, void* stream) {
+    if (!z || !y || !scale || !shift || !gate_out || !dtype_ok(dtype) || N <= 0 || HW <= 0) return ERF_EINVAL;
+    return bn_apply_launch(z, y, center, scale, shift, residual, mask, dtype, (long long)N * HW, C, HW, relu, (hipStream_t)stream,
+                           (unsigned char*)gate_out);
+}
+
 int erf_bn_backward(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
                     const float* invstd, const float* gamma, int batch_stats, void* dz, void* g_out, float* dgamma,
                     float* dbeta, int dtype, int N, long long HW, int C, void* workspace, void* stream) {
@@ -120,10 +129,10 @@ int erf_conv1d_dgrad_bias(const void* dy, void* dx, const void* packed_t, const 
 
 // dx = gate(conv1d_dgrad(dy) + residual), then the backward pass of the BatchNorm whose output gradient dx is:
 // its two reductions ride in the convolution's epilogue, so only the apply pass reads dx again.
-int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual,
-                                 int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
-                                 const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
-                                 int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
+static int dgrad_bn_backward(const void* dy, void* dx, const void* packed_t, const void* gate, int gate_bits, const void* residual,
+                             int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
+                             const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
+                             int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
     if (!dy || !dx || !packed_t || !gate || !bn_z || !bn_mean || !bn_invstd || !bn_gamma || !dz || !dgamma || !dbeta ||
         !workspace || !dtype_ok(dtype) || N <= 0 || H <= 0 || W <= 0 || dilation < 1)
         return ERF_EINVAL;
@@ -131,7 +140,7 @@ int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t,
     Conv1dBnTail tail{bn_z, bn_mean, bn_invstd, bn_mask, 1};
     int groups = 0;
     int rc = conv1d_buf_launch(dy, dx, packed_t, nullptr, nullptr, residual, gate, (double*)workspace, &groups, dtype, N, H, W, C,
-                               axis, dilation, 0, (hipStream_t)stream, &tail);
+                               axis, dilation, 0, (hipStream_t)stream, &tail, gate_bits);
     if (rc) return rc;
     const long long P = (long long)N * H * W;
     float* coef = bn_workspace_coef(workspace, C);
@@ -140,6 +149,23 @@ int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t,
     if (rc) return rc;
     return bn_bwd_apply_launch(dx, nullptr, bn_mask, bn_z, bn_mean, bn_invstd, coef, dz, nullptr, dtype, P, C, (long long)H * W,
                                (hipStream_t)stream);
+}
+
+int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t, const void* gate, const void* residual,
+                                 int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
+                                 const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
+                                 int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    return dgrad_bn_backward(dy, dx, packed_t, gate, 0, residual, dtype, N, H, W, C, axis, dilation, bn_z, bn_mean, bn_invstd, bn_gamma,
+                             bn_mask, batch_stats, dz, dgamma, dbeta, workspace, stream);
+}
+
+// The same with the gate given as erf_bn_apply_gates wrote it: one byte per 16-byte chunk of the gating tensor
+int erf_conv1d_dgrad_bn_backward_bits(const void* dy, void* dx, const void* packed_t, const void* gate_bits, const void* residual,
+                                      int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
+                                      const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
+                                      int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    return dgrad_bn_backward(dy, dx, packed_t, gate_bits, 1, residual, dtype, N, H, W, C, axis, dilation, bn_z, bn_mean, bn_invstd,
+                             bn_gamma, bn_mask, batch_stats, dz, dgamma, dbeta, workspace, stream);
 }
 
 // erf_conv1d_dgrad_bias without its last step: the partial rows stay in `workspace` (the return value is their number,

@@ -27,7 +27,7 @@ struct Conv1dBnTail {
 // with `tail`, (sum y*m, sum y*m*xhat) -- the partial rows bn_bwd_finalize_launch takes.
 int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, const void* residual,
                       const void* gate, double* stats, int* groups, int dtype, int N, int H, int W, int C, int axis, int dilation,
-                      int relu, hipStream_t stream, const Conv1dBnTail* tail = nullptr);
+                      int relu, hipStream_t stream, const Conv1dBnTail* tail = nullptr, int gate_bits = 0);
 int conv1d_buf_max_groups();
 
 // A whole non_bottleneck_1d block (four factorized convolutions, folded BatchNorms, residual) in one launch, bf16, dilation 1.

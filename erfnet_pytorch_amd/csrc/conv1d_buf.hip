@@ -30,6 +30,7 @@ struct BufParams {
     const float* shift;
     const void* res;
     const void* gate;
+    int gate_bits;          // gate is one byte per 16-byte chunk of the tensor (bit e = [value e > 0]) instead of the tensor
     double* stats;          // [grid][2C] partial rows, or null: (sum, sum of squares) of y, or the two sums below
     // BatchNorm-backward sums of y taken as the gradient at a BatchNorm's output (null bz: off):
     //   row = (sum y*m, sum y*m*xhat), xhat = (bz - bmean) * binvstd, m = bmask[image][channel] (null: 1)
@@ -114,7 +115,7 @@ void conv1d_buf_kernel(const BufParams p) {
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc((const char*)p.x - p.pad, p.bytes + p.pad);
     const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y, p.bytes);
     const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.res ? p.res : p.x, p.bytes);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.gate ? p.gate : p.x, p.bytes);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.gate ? p.gate : p.x, p.gate && p.gate_bits ? p.bytes >> 4 : p.bytes);
     const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(p.bz ? p.bz : p.x, p.bytes);
 
     i32x4 wreg[CTW][KS];
@@ -325,6 +326,43 @@ void conv1d_buf_kernel(const BufParams p) {
             outv[s] = *(const i32x4*)(smem + boff + rb_lds[s]);
         }
         if constexpr (POST) {
+            bool gated_by_bits = false;
+            if constexpr (sizeof(T) == 2) if (p.gate && p.gate_bits) {
+                gated_by_bits = true;
+                // the gate as one byte per chunk (bit e = [value e > 0]): a sixteenth of the bytes of the tensor it stands for
+                uint32_t gb[NS];
+                u32x4 rv[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    gb[s] = __builtin_amdgcn_raw_buffer_load_b8(rs_g, ooff[s] == ERF_OOB ? ERF_OOB : ooff[s] >> 4, g.soff >> 4, 0);
+                if (p.res) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) rv[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ooff[s], g.soff, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    float f[EPC];
+                    ChunkOps<T>::unpack(outv[s], f);
+                    if (p.res) {
+                        float r[EPC];
+                        ChunkOps<T>::unpack(__builtin_bit_cast(i32x4, rv[s]), r);
+                        if (p.gate_after) {
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) f[e] = (gb[s] >> e) & 1u ? f[e] + r[e] : 0.f;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) f[e] = ((gb[s] >> e) & 1u ? f[e] : 0.f) + r[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] = (gb[s] >> e) & 1u ? f[e] : 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[e] = fmaxf(f[e], floor_v);
+                    outv[s] = ChunkOps<T>::pack(f);
+                }
+            }
+            if (!gated_by_bits) {
             // one operand in the common case (gate: ReLU backward; residual: skip connection), both allowed
             u32x4 pv[NS];
             const bool both = p.gate && p.res;
@@ -357,6 +395,7 @@ void conv1d_buf_kernel(const BufParams p) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) f[e] = fmaxf(f[e], floor_v);
                 outv[s] = ChunkOps<T>::pack(f);
+            }
             }
         }
         if constexpr (STATS == 1) {
@@ -510,12 +549,13 @@ int conv1d_buf_max_groups() { return 512; }
 
 int conv1d_buf_launch(const void* x, void* y, const void* packed, const float* scale, const float* shift, const void* residual,
                       const void* gate, double* stats, int* groups, int dtype, int N, int H, int W, int C, int axis, int dilation,
-                      int relu, hipStream_t stream, const Conv1dBnTail* tail) {
+                      int relu, hipStream_t stream, const Conv1dBnTail* tail, int gate_bits) {
     static const int off = erf_debug_env("ERF_CONV1D_BUF_OFF", 0);
     if (off) return ERF_EUNSUPPORTED;
     BufParams p{};
     p.x = x; p.y = y; p.w = packed; p.scale = scale; p.shift = shift; p.res = residual; p.gate = gate; p.stats = stats;
-    p.d = dilation; p.relu = relu;
+    p.d = dilation; p.relu = relu; p.gate_bits = gate && gate_bits;
+    if (p.gate_bits && dtype != 1) return ERF_EUNSUPPORTED;       // the byte-per-chunk gate is read by the bf16 instances only
     if (tail) {
         p.bz = tail->z; p.bmean = tail->mean; p.binvstd = tail->invstd; p.bmask = tail->mask; p.gate_after = tail->gate_after;
     }

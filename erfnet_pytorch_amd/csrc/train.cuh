@@ -18,7 +18,7 @@ int bn_finalize_launch(const float* partials, int groups, int C, long long count
                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                        float* scale, float* shift, hipStream_t stream);
 int bn_apply_launch(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* res, const float* mask,
-                    int dtype, long long P, int C, long long HW, int relu, hipStream_t stream);
+                    int dtype, long long P, int C, long long HW, int relu, hipStream_t stream, unsigned char* gate_out = nullptr);
 int bn_bwd_reduce_launch(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
                          const float* invstd, int dtype, long long P, int C, long long HW, float* partials, int* groups,
                          hipStream_t stream);

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const i32x4* __rest
                                                              const float* __restrict__ center, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const i32x4* __restrict__ res,
                                                              const float* __restrict__ mask, uint32_t total, int C, FastDiv fCv,
-                                                             FastDiv fHW, int relu) {
+                                                             FastDiv fHW, int relu, unsigned char* __restrict__ gate_out) {
     constexpr int E = ChunkOps<T>::N;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t p = fast_div(i, fCv);
@@ -295,7 +295,18 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const i32x4* __rest
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        y[i] = ChunkOps<T>::pack(v);
+        const i32x4 packed = ChunkOps<T>::pack(v);
+        y[i] = packed;
+        if (gate_out) {
+            // one byte per 16-byte chunk: bit e = [stored value e > 0], what a ReLU backward needs of this tensor -- taken from
+            // the ROUNDED values, so that it equals the test on the tensor itself
+            float w[E];
+            ChunkOps<T>::unpack(packed, w);
+            unsigned bits = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) bits |= (w[e] > 0.f ? 1u : 0u) << e;
+            gate_out[i] = (unsigned char)bits;
+        }
     }
 }
 
@@ -349,7 +360,7 @@ static unsigned ew_grid(long long total) {
 }
 
 int bn_apply_launch(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* res, const float* mask,
-                    int dtype, long long P, int C, long long HW, int relu, hipStream_t stream) {
+                    int dtype, long long P, int C, long long HW, int relu, hipStream_t stream, unsigned char* gate_out) {
     if (C & 3) return ERF_EUNSUPPORTED;
     if (dtype == 1 ? vec_shape_ok<bf16raw>(P, C, HW) : vec_shape_ok<float>(P, C, HW)) {
         const int cv = C / (dtype == 1 ? 8 : 4);
@@ -357,12 +368,13 @@ int bn_apply_launch(const void* z, void* y, const float* center, const float* sc
         const FastDiv fCv = make_fastdiv(cv), fHW = make_fastdiv((int)HW);
         if (dtype == 1)
             hipLaunchKernelGGL(affine_act_vec_kernel<bf16raw>, dim3(ew_grid(total)), dim3(256), 0, stream, (const i32x4*)z, (i32x4*)y,
-                               center, scale, shift, (const i32x4*)res, mask, (uint32_t)total, C, fCv, fHW, relu);
+                               center, scale, shift, (const i32x4*)res, mask, (uint32_t)total, C, fCv, fHW, relu, gate_out);
         else
             hipLaunchKernelGGL(affine_act_vec_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, stream, (const i32x4*)z, (i32x4*)y,
-                               center, scale, shift, (const i32x4*)res, mask, (uint32_t)total, C, fCv, fHW, relu);
+                               center, scale, shift, (const i32x4*)res, mask, (uint32_t)total, C, fCv, fHW, relu, gate_out);
         return erf_check_launch();
     }
+    if (gate_out) return ERF_EUNSUPPORTED;            // gate bytes are per 16-byte chunk: the chunked kernel only
     const long long total4 = P * (C / 4);
     if (dtype == 1)
         hipLaunchKernelGGL(affine_act_kernel<bf16raw>, dim3(ew_grid(total4)), dim3(256), 0, stream, (const bf16raw*)z,

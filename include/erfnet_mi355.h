@@ -189,6 +189,12 @@ int erf_bn_stats_finalize(const void* z, int dtype, long long pixels, int C, con
                           float* scale, float* shift, void* workspace, void* stream);
 int erf_bn_apply(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* residual,
                  const float* mask, int dtype, int N, long long HW, int C, int relu, void* stream);
+/* erf_bn_apply that also writes the ReLU gate of its output (what F.relu's backward needs of it, train/erfnet.py:63,74): one
+ * byte per 16-byte chunk of y, bit e = [y value e > 0] (bf16: 8 channels per byte, fp32: 4; N*HW*C*sizeof(T)/16 bytes),
+ * taken from the stored, rounded values.  C a multiple of the chunk.  erf_conv1d_dgrad_bn_backward_bits reads it in place of
+ * the tensor: a sixteenth of the bytes. */
+int erf_bn_apply_gates(const void* z, void* y, const float* center, const float* scale, const float* shift, const void* residual,
+                       const float* mask, int dtype, int N, long long HW, int C, int relu, void* gate_out, void* stream);
 int erf_bn_backward(const void* g, const void* gate, const float* mask, const void* z, const float* mean,
                     const float* invstd, const float* gamma, int batch_stats, void* dz, void* g_out, float* dgamma,
                     float* dbeta, int dtype, int N, long long HW, int C, void* workspace, void* stream);
@@ -412,6 +418,12 @@ int erf_conv1d_dgrad_bn_backward(const void* dy, void* dx, const void* packed_t,
                                  int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
                                  const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
                                  int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
+/* erf_conv1d_dgrad_bn_backward with the gate as erf_bn_apply_gates wrote it (one byte per 16-byte chunk of the gating tensor);
+ * same results bit for bit. */
+int erf_conv1d_dgrad_bn_backward_bits(const void* dy, void* dx, const void* packed_t, const void* gate_bits, const void* residual,
+                                      int dtype, int N, int H, int W, int C, int axis, int dilation, const void* bn_z,
+                                      const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_mask,
+                                      int batch_stats, void* dz, float* dgamma, float* dbeta, void* workspace, void* stream);
 
 /* ---- classifier head of the ImageNet pre-training variant, train/erfnet_imagenet.py:97-120 ----
  * Features.forward after the encoder: MaxPool2d(2, stride 2) -> AvgPool2d(14, 1, 0) on the 28x28 map

@@ -1,20 +1,23 @@
-"""A/B of Trainer options on one box: wall time per step and host enqueue time per step (time until step() returns)."""
-import sys, time, torch
-sys.path.insert(0, ".")
-from erfnet_pytorch_amd import erfnet as E, synthetic as S
+"""A/B of a module switch of the training path on one box: wall time per replayed step (batch 6, 3x512x1024, bf16).
+usage: train_ab.py [SWITCH=GATE_BITS]   -- a boolean attribute of erfnet_pytorch_amd.autograd"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from erfnet_pytorch_amd import erfnet as E, synthetic as S, autograd as ag
 from erfnet_pytorch_amd.trainer import Trainer, CITYSCAPES_WEIGHTS
+switch = sys.argv[1] if len(sys.argv) > 1 else "GATE_BITS"
 dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev).manual_seed(1234)
 x = torch.randn(6, 3, 512, 1024, device=dev, generator=gen)
 t = torch.randint(0, 20, (6, 1, 512, 1024), device=dev, generator=gen)
-for rep in range(2):
-    for fused in (True, False):
+for rep in range(3):
+    for on in (True, False):
+        setattr(ag, switch, on)
         m = E.ERFNet(20); S.load_synthetic(m); m = m.to(dev).train(); m.compute_dtype = torch.bfloat16
-        tr = Trainer(m, CITYSCAPES_WEIGHTS, fused_head_loss=fused)
-        for _ in range(5): tr.step(x, t)
+        tr = Trainer(m, CITYSCAPES_WEIGHTS, graph=True)
+        for _ in range(6): tr.step(x, t)
         torch.cuda.synchronize()
-        t0 = time.perf_counter(); host = 0.0
-        for _ in range(30):
-            h0 = time.perf_counter(); tr.step(x, t); host += time.perf_counter() - h0
+        t0 = time.perf_counter()
+        for _ in range(30): loss, _ = tr.step(x, t)
         torch.cuda.synchronize()
-        print(f"fused={fused} wall {1e3*(time.perf_counter()-t0)/30:.2f} ms/step, host enqueue {1e3*host/30:.2f} ms/step", flush=True)
+        print(f"{switch}={on}: {1e3*(time.perf_counter()-t0)/30:.3f} ms/step  loss {float(loss):.5f}", flush=True)
+        del tr, m

@@ -825,3 +825,65 @@ def test_out_of_range_target_poisons_the_loss(fused):
         t_bad = t.clone(); t_bad[0, 5, 7] = bad
         loss, gb = run(t_bad)
         assert np.isnan(loss) and torch.isnan(gb).any(), bad
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 128, 256)])
+def test_relu_gates_as_bytes_give_the_same_bits_as_the_tensors(shape):
+    """The BatchNorm-apply passes write the ReLU gate of their output as one byte per 16-byte chunk, and the fused
+    data-gradient launches read those bytes instead of the tensor (a sixteenth of the traffic).  The gate is an exact
+    predicate of the stored values, so every gradient, the logits and the running statistics are the same BITS with the
+    switch on and off; the counter shows that the byte form is the one that ran."""
+    from erfnet_pytorch_amd import erfnet as E
+    from erfnet_pytorch_amd import autograd as ag
+    sd = O.synthetic_state(O.erfnet_template(20))
+    n, h, w = shape
+    x = S.synthetic_images(n, h, w, seed=57).to(DEV)
+    up = upstream((n, 20, h, w), 57).to(DEV)
+
+    def run(bits):
+        m = E.ERFNet(20)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        m.compute_dtype = torch.bfloat16
+        for mod in m.modules():
+            if isinstance(mod, E.non_bottleneck_1d) and mod.dropout.p != 0:
+                gen = torch.Generator().manual_seed(mod.conv3x1_1.out_channels + mod.dilated)
+                keep = (torch.rand(n, mod.conv3x1_1.out_channels, generator=gen) > mod.dropout.p).float()
+                mod.__dict__["_erf_forced_mask"] = keep / (1 - mod.dropout.p)
+        old, ag.GATE_BITS = ag.GATE_BITS, bits
+        n0 = ag.GATE_BITS_CALLS[0]
+        try:
+            y = m(x)
+            y.backward(up)
+        finally:
+            ag.GATE_BITS = old
+        return m, y.detach(), ag.GATE_BITS_CALLS[0] - n0
+
+    ma, ya, na = run(True)
+    mb, yb, nb = run(False)
+    assert nb == 0 and na >= 24, (na, nb)
+    assert torch.equal(ya, yb)
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), k
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), k
+    for (k, a), (_, b) in zip(ma.named_buffers(), mb.named_buffers()):
+        assert torch.equal(a, b), k
+
+
+def test_bn_apply_gate_bytes_against_the_tensor():
+    """erf_bn_apply_gates: bit e of byte i = [element 8 i + e of the output > 0], output equal to erf_bn_apply's; ragged sizes."""
+    from erfnet_pytorch_amd import autograd as ag
+    for n, h, w, c in ((2, 5, 7, 64), (1, 3, 9, 16), (3, 4, 4, 128)):
+        g = torch.Generator().manual_seed(c + h)
+        z = torch.randn(n, h, w, c, generator=g).to(torch.bfloat16).to(DEV)
+        res = torch.randn(n, h, w, c, generator=g).to(torch.bfloat16).to(DEV)
+        scale, shift, center = (torch.randn(c, generator=g).to(DEV) for _ in range(3))
+        mask = (torch.rand(n, c, generator=g) > 0.3).float().to(DEV)
+        for r, mk in ((None, None), (res, mask)):
+            y, bits = ag.bn_apply_gates(z, center, scale, shift, r, mk)
+            assert bits is not None and bits.numel() == z.numel() // 8
+            assert torch.equal(y, ag.bn_apply(z, center, scale, shift, r, mk, True))
+            want = (y.reshape(-1, 8).float() > 0).to(torch.int32)
+            want = (want << torch.arange(8, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+            assert torch.equal(bits, want)
