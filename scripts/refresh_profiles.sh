@@ -22,6 +22,7 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BU
 cd "$ROOT"
 cp "$(ls $OUT/trace/*/*kernel_stats.csv | tail -1)" profiles/${ROUND}_bench_kernel_stats.csv
 cp "$(ls $OUT/trace2/*/*kernel_stats.csv | tail -1)" profiles/${ROUND}_bench_kernel_stats_two_chains.csv
+python3 scripts/block_context.py "$OUT/trace" profiles/${ROUND}_block_kernel_by_context.csv > /dev/null
 python3 scripts/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" profiles/${ROUND}_pmc_traffic
 python3 scripts/pmc_mfma.py "$OUT/pmc_mfma" profiles/${ROUND}_pmc_mfma.csv > "$OUT/mfma.txt"
 cp profiles/${ROUND}_* "$OUT/"
