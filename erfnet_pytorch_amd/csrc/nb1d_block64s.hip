@@ -90,11 +90,16 @@ struct NbStreamParams {
                              // 8 no x requests, 16 no fragment reads, 256 cycle stamps
 };
 
-#ifdef ERF_DEBUG
+#ifdef NBS_ABLATE
+// ablation builds (-DNBS_ABLATE=mask, same bits as ERF_BLOCK_DBG): parts of a step removed at COMPILE time, so that what is left
+// runs exactly as in the product build (the run-time switches of the debug build cost a step more than they remove)
+#define NBS_DBG(bit) ((NBS_ABLATE) & (bit))
+#define NBS_STAMP(i)
+#elif defined(ERF_DEBUG)
 // cycle stamps of a diagnostic build: [workgroup][wave][section], read back by erf_debug_block64s_stamps; nothing else reads them
 static __device__ unsigned long long g_nbs_stamps[256 * 8 * 8];
 #define NBS_DBG(bit) (p.dbg & (bit))
-#define NBS_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); st[i] += tn - tprev; tprev = tn; }
+#define NBS_STAMP(i) if (p.dbg & 256) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); st[i] += tn - tprev; tprev = tn; }
 #else
 #define NBS_DBG(bit) 0
 #define NBS_STAMP(i)
