@@ -439,8 +439,10 @@ int erf_linear_bwd(const float* f, const float* w, const float* dy, float* df, f
 
 /* ---- peak probes (no counterpart in the reference, which times whole forward passes only: eval/eval_forwardTime.py:40-59) ----
  * What this part sustains on the two resources the roofline fractions are priced against.  erf_probe_mfma: a
- * matrix-instruction-only loop (dtype 1: v_mfma_f32_16x16x32_bf16, 0: v_mfma_f32_16x16x4_f32; `workgroups` of 8 waves, `iters`
- * trips of 8 independent chains per wave); erf_probe_mfma_flop: the flop such a launch executes.  erf_probe_copy: streaming copy of `bytes` (multiple of 16) by `workgroups` x 256 lanes. */
+ * matrix-instruction-only loop (dtype 1: v_mfma_f32_16x16x32_bf16 on constant operands, 2: the same on operands that differ
+ * in every lane and register, 0: v_mfma_f32_16x16x4_f32; `workgroups` of 8 waves, `iters` trips of 8 independent chains per
+ * wave; `sink`: 4 floats -- [1] and [2] receive how far s_memtime and the 100 MHz s_memrealtime moved over workgroup 0's loop);
+ * erf_probe_mfma_flop: the flop such a launch executes.  erf_probe_copy: streaming copy of `bytes` (multiple of 16) by `workgroups` x 256 lanes. */
 long long erf_probe_mfma_flop(int dtype, int workgroups, int iters);
 int erf_probe_mfma(int dtype, int workgroups, int iters, float* sink, void* stream);
 int erf_probe_copy(const void* src, void* dst, long long bytes, int workgroups, void* stream);
