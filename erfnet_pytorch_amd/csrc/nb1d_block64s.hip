@@ -54,6 +54,10 @@
 
 typedef bf16raw T;
 
+#ifndef NBS_MIN_ROWS
+#define NBS_MIN_ROWS 40          // fewest rows of a workgroup's run (see the launcher)
+#endif
+
 namespace nbs {
 constexpr int C = 64, PIXB = 128, KS = 6, CT = 4;
 constexpr int FW = 64, TW = 60;                     // frame / output columns of a strip
@@ -457,7 +461,7 @@ int nb1d_block64s_launch(const void* x, void* y, const void* const* packed4, con
     if (rows > (long long)MAX_WGS * (MAX_SLOTS - 8)) return ERF_EUNSUPPORTED;     // more rows than 256 slot tables hold
     const double NARROW_COST = erf_debug_env("ERF_NBS_NARROW_COST", 850) * 1e-3;
     int want = MAX_WGS;
-    if (rows < (long long)MAX_WGS * 40) want = (int)((rows + 39) / 40);
+    if (rows < (long long)MAX_WGS * NBS_MIN_ROWS) want = (int)((rows + NBS_MIN_ROWS - 1) / NBS_MIN_ROWS);
     const long long ncols = (long long)N * p.S;
     auto col_cost = [&](long long cid) { return (p.narrow_last && cid % p.S == p.S - 1) ? NARROW_COST : 1.0; };
     double total = 0;
