@@ -456,6 +456,8 @@ def _labels_from_u8(src, olabel, nlabel):
     (olabel < 0: conversion only)."""
     if src.dtype != torch.uint8 or not src.is_contiguous():
         raise TypeError("labels_from_u8: a contiguous uint8 tensor")
+    if src.data_ptr() % 16:                       # a slice that starts inside a 16-byte group: the kernel reads whole groups
+        src = src.clone()
     dst = torch.empty(src.shape, dtype=torch.int64, device=src.device)
     call("erf_labels_from_u8", src.data_ptr(), dst.data_ptr(), src.numel(), int(olabel), int(nlabel), _stream())
     return dst

@@ -109,6 +109,8 @@ def test_uint8_label_images_with_relabel_equal_the_loaders_target_transform(shap
     got = ops.labels_from_u8(raw.to(DEV), (255, 19))
     assert got.dtype == torch.int64 and torch.equal(got.cpu(), gold[:, 0])
     assert torch.equal(ops.labels_from_u8(raw.to(DEV)).cpu(), raw.long())
+    flat = raw.reshape(-1).to(DEV)
+    assert torch.equal(ops.labels_from_u8(flat[3:], (255, 19)).cpu(), gold.reshape(-1)[3:])      # a slice off the 16-byte grid
     ref = iouEval(20)
     ref.addBatch(pred.unsqueeze(1).to(DEV), gold.to(DEV))
     tp, fp, fn = O.iou_counts(pred.unsqueeze(1), gold, 20)
