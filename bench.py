@@ -10,14 +10,20 @@ N = 1, headline (`value`): BASELINE.json configs[1] -- ERFNet(20) inference, bat
   The same line carries
     "inference_one_chain" the same leg with one chain of launches (short leg),
     "training"       BASELINE.json configs[2]: the bf16 training step, batch 6 (its own steps / warm-up),
-    "inference_with_h2d" the headline pipeline fed from pinned HOST memory: uint8 images on a copy stream, double-buffered,
-                     ToTensor()'s / 255 applied by the initial block on load (PCIe-inclusive; never `value`),
+    "inference_with_h2d" the headline pipeline fed from pinned HOST memory: uint8 images + uint8 label images on a copy stream,
+                     double-buffered, ToTensor()'s / 255 applied by the initial block on load and Relabel(255, 19) by the
+                     histogram while counting (PCIe-inclusive; never `value`); the copy stream is the fastest of four
+                     fresh ones (`copy_stream_trials_ms`: a copy stream that shares a hardware queue with a compute stream
+                     takes turns with its kernels),
     "fp32"           {"inference", "training"}: the same two legs with fp32 storage (short legs),
-    "roofline"       the dominant kernel alone (full-batch launches, one chain), timed here with events on the launch stream,
+    "roofline"       the dominant kernel (full-batch launches, one chain), timed here with events on the launch stream: the time
+                     a replayed forward pass gains when one more pass over the kernel's launches is appended (`avg_launch_us`,
+                     what a launch costs inside a step) and the same launches back to back (`avg_launch_us_back_to_back`),
     "roofline_block" the same measurement priced per non_bottleneck_1d block against the block's algorithmic bytes
                      (x in, y out), which shows what the two-launch block spends above the one-pass model,
     "cpu_baseline"   the oracle's fp32 forward, b=1, on this box's host cores (eval_forwardTime protocol).
-    "measured_peak"  what this GPU sustains on an MFMA-only loop (bf16, fp32) and on a streaming copy (erfnet_pytorch_amd/probe.py);
+    "measured_peak"  what this GPU sustains on an MFMA-only loop (bf16 on constant and on varied operands, fp32) and on a
+                     streaming copy (erfnet_pytorch_amd/probe.py);
                      every roofline object carries `frac_of_measured` beside `frac` (which is against the nominal peak).
 N > 1, headline: the data-parallel TRAINING step of configs[2]
   -- batch 6 per GPU, weighted cross-entropy, Adam, gradient all-reduce over RCCL inside the timed region ("weak"
